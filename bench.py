@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the MI355X ray-casting path.
+
+One "step" = one 1920x1080 frame of primary rays over maps/dragon.vox (BASELINE.json config 3, the
+configuration its metric is quoted on), octree and camera already resident in HBM. With N GPUs the
+frame's rows are dealt in 8-row tiles to the ranks (one process per GPU), each rank traces its
+tiles, and the finished rows are gathered to rank 0 over RCCL -- the gather is inside the timed step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode primary|primary_shadow]
+                    [--map dragon|monu9|nature] [--width 1920 --height 1080] [--variant V]
+
+Rank 0 prints ONE JSON line (contract in the repository README / DESIGN.md section "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+POSES = {  # framing poses of SURVEY.md 8(d): x, y, z, yaw, pitch
+    "dragon": (63.5, 60.5, 140.5, -90.0, -10.0),
+    "monu9": (48.5, 60.5, 170.5, -90.0, -12.0),
+    "nature": (60.5, 80.5, 200.5, -90.0, -20.0),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(args, tex, dim, cam, budget_s=12.0):
+    """Times the CPU restatement (oracle/, a scalar single-thread port of the same traversal) on whole
+    frames of the same workload until ~budget_s of CPU work is done. Reported, never the target."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    O.build()
+    s = O.make_scene(tex, dim, *cam)
+    mode = {"primary": 0, "primary_shadow": 1}[args.mode]
+    W, H = args.width, args.height
+    band = max(8, H // 8)
+    t0 = time.perf_counter()
+    rays = 0
+    passes = 0
+    r = 0
+    # bounded sample: successive bands of rows of the bench frame, cycling over the frame
+    while time.perf_counter() - t0 < budget_s:
+        r0 = r % H
+        r1 = min(H, r0 + band)
+        O.render(s, W, H, mode, row0=r0, row1=r1)
+        rays += (r1 - r0) * W
+        r = r1 % H
+        passes += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "sample": f"{rays} primary rays of the same frame ({passes} bands of {band} rows, cycling) in {dt:.1f} s, "
+                      f"oracle/rt_oracle.c -O2 -ffp-contract=off, 1 thread of {os.cpu_count()} host cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--mode", default="primary", choices=["primary", "primary_shadow"])
+    ap.add_argument("--map", default="dragon", choices=sorted(POSES))
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--tile-rows", type=int, default=8)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import vrt_import
+    V = vrt_import.vrt()
+    shd = __import__("importlib").import_module("voxel-raytracer_amd.sharding")
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the ray-casting path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    # host side of the path: .vox -> octree -> texel stream; camera block (all through the product library)
+    wld = V.World()
+    if not wld.load_vox(os.path.join(ROOT, "tests", "golden", "maps", args.map + ".vox")):
+        raise SystemExit("cannot load the scene fixture")
+    tex, dim = wld.flatten()
+    pose = POSES[args.map]
+    W, H = args.width, args.height
+    ip, iv, cp, _ = V.camera_block(pose[:3], pose[3], pose[4], W, H)
+    mode = V.MODES[args.mode]
+
+    ctx = V.Context(local_rank)
+    ctx.set_variant(args.variant)
+    ctx.upload_octree(tex, dim)
+    ctx.set_camera(ip, iv, cp)
+
+    plan = shd.ShardPlan(W, H, args.tile_rows, rank, world)
+    local = plan.local_buffer(dev)
+    p_rgba, p_id = plan.pointers(local)
+    gathered = [torch.empty_like(local) for _ in range(world)] if (rank == 0 and world > 1) else None
+    frame_rgba = torch.zeros((H, W), dtype=torch.int32, device=dev) if rank == 0 else None
+    frame_id = torch.zeros((H, W, 2), dtype=torch.int32, device=dev) if rank == 0 else None
+    row_index = plan.frame_index(dev) if rank == 0 else None
+    stream = torch.cuda.current_stream(dev).cuda_stream  # launch on torch's stream so the gather orders after it
+
+    def step():
+        ctx.dispatch_shard(W, H, args.tile_rows, rank, world, mode, p_rgba, p_id, stream)
+        if world > 1:
+            shd.gather_frame(plan, local, gathered, frame_rgba, frame_id, row_index)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.set_profiling(args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ctx.profile_read(args.steps)
+    ctx.set_profiling(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # frame assembled once more outside the timed region for the self-check (N=1 path has no gather in step())
+    if world == 1:
+        shd.gather_frame(plan, local, None, frame_rgba, frame_id, row_index)
+    torch.cuda.synchronize(dev)
+
+    if rank == 0:
+        frames = json.load(open(os.path.join(ROOT, "tests", "golden", "frames.json")))["frames"]
+        key = {"dragon": "dragon_1080p", "monu9": "monu9_720p", "nature": "nature_4k"}[args.map] + f"/mode{mode}"
+        g = frames.get(key)
+        known = g is not None and (g["width"], g["height"]) == (W, H)
+        rgba_host = frame_rgba.cpu().numpy().view("uint8").reshape(H, W, 4)
+        id_host = frame_id.cpu().numpy()
+        check = None
+        if known:
+            check = ("%016x" % V.fnv1a64(rgba_host) == g["rgba_fnv1a64"] and
+                     "%016x" % V.fnv1a64(id_host) == g["id_dist_fnv1a64"])
+        rays = W * H
+        ms_per_step = elapsed / args.steps * 1e3
+        value = rays * args.steps / elapsed / 1e6
+        roofline = None
+        if known and len(kernel_ms):
+            # algorithmic bytes of THIS rank's launch: 4 B per texel fetch the reference algorithm issues for
+            # the rows it traces + 12 B per pixel written; exact per-row counts are committed
+            if "row_fetches" in g:
+                f_local = sum(g["row_fetches"][r] for r in plan.rows_of[0])
+            else:
+                f_local = g["fetches"] * plan.rows_local // H
+            b_algo = 4 * f_local + 12 * W * plan.rows_local
+            avg_ms = float(kernel_ms.mean())
+            achieved = b_algo / (avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "kernel": "trace_kernel", "kernel_avg_ms": round(avg_ms, 5),
+                        "algorithmic_bytes_per_launch": b_algo,
+                        "compulsory_bytes_per_launch": int(tex.size + 12 * W * plan.rows_local)}
+        out = {
+            "metric": "Mrays/s at 1920x1080 primary rays; achieved HBM GB/s vs peak",
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32",
+            "data": f"tests/golden/maps/{args.map}.vox scene fixture, fixed synthetic camera pose",
+            "config": {"workload": f"{args.map}.vox {W}x{H} {args.mode} rays, pose {pose}", "mode": args.mode,
+                       "sharding": f"interleaved {args.tile_rows}-row tiles over {world} rank(s), gather to rank 0 in-step",
+                       "variant": args.variant},
+            "roofline": roofline,
+            "pixels_match_oracle_golden": check,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, tex, dim, (ip, iv, cp))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,135 @@
+/*
+ * vrt.h -- C-ABI of the MI355X (gfx950) ray-casting layer: libvrt_hip.so.
+ *
+ * Drop-in boundary for the compute-shader dispatch of pedroand6/Voxel-Raytracer.
+ * Each entry point replaces one piece of the reference's GL plumbing around
+ * `glDispatchCompute` (reference paths are relative to the upstream repo root):
+ *
+ *   vrt_create / vrt_destroy   GL object setup/teardown        src/main.cpp:432-474, 973-983
+ *   vrt_upload_octree          updateGPUTexture()/glTexImage3D src/main.cpp:264-311
+ *   vrt_set_camera             Camera UBO glBufferSubData      src/main.cpp:643-656, 807-813, 916-917
+ *   vrt_set_params             the seven glUniform* calls      src/main.cpp:689-695, 932-938
+ *   vrt_dispatch*              glMemoryBarrier+glDispatchCompute src/main.cpp:941-946
+ *                              (shader: shaders/raytracing.comp:624-645)
+ *
+ * Plain pointers and sizes only; no C++/torch types cross this boundary and no
+ * exception escapes. Every call returns 0 on success or a negative VRT_E_*;
+ * vrt_last_error() gives the text. One context per host thread (thread-
+ * compatible, not thread-safe). There is no CPU fallback: without a HIP device
+ * vrt_create fails with VRT_E_NO_DEVICE.
+ */
+#ifndef VRT_H
+#define VRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VRT_OK 0
+#define VRT_E_INVALID (-1)    /* bad argument */
+#define VRT_E_NO_DEVICE (-2)  /* no usable HIP device / HIP runtime error at create */
+#define VRT_E_HIP (-3)        /* HIP runtime call failed */
+#define VRT_E_MALFORMED (-4)  /* texel stream cannot be a flattened octree */
+#define VRT_E_STATE (-5)      /* call order (e.g. dispatch before upload) */
+
+/* which subset of pathTrace (raytracing.comp:435-622) a dispatch evaluates */
+#define VRT_MODE_PRIMARY 0         /* primary ray, direct term unshadowed */
+#define VRT_MODE_PRIMARY_SHADOW 1  /* + notInShadow() ray per opaque hit (comp:333-377, 587) */
+#define VRT_MODE_FULL 2            /* the whole shader: glass stack, diffuse bounce, RNG */
+
+typedef struct vrt_ctx vrt_ctx;
+
+/* The shader's scalar uniforms (raytracing.comp:27-39). u_texDim travels with
+ * vrt_upload_octree. Defaults = the values src/main.cpp:478-483,638 sets. */
+typedef struct vrt_params {
+    float voxel_scale;          /* u_voxelScale            (1.0)              */
+    int32_t world_min[3];       /* u_worldBoundsMin        (-1023,-1023,-1023) */
+    int32_t world_max[3];       /* u_worldBoundsMax        (1024,1024,1024)    */
+    float global_light[4];      /* globalLight             (1,1,1,1)           */
+    float light_dir[3];         /* lightDir  normalize(.3481553,.870388,.3481553) */
+    int32_t highlighted[3];     /* u_highlightedVoxel      (-1,-1,-1)          */
+} vrt_params;
+
+typedef struct vrt_scene_info {
+    uint32_t tex_dim;           /* u_texDim given at upload */
+    uint32_t n_texels;          /* texels in the uploaded stream */
+    uint32_t n_records;         /* 8-byte device records (internal + leaf) */
+    uint32_t n_internal;        /* internal nodes */
+    uint32_t n_leaves;          /* leaf nodes */
+    uint32_t max_depth;         /* deepest node below the root */
+    uint32_t lds_records;       /* records of the level-order prefix staged in LDS */
+    uint32_t reserved;
+} vrt_scene_info;
+
+int vrt_create(int device_id, vrt_ctx **out);
+void vrt_destroy(vrt_ctx *ctx);
+/* ctx may be NULL: returns the message of the last failed vrt_create on this thread */
+const char *vrt_last_error(const vrt_ctx *ctx);
+
+/* Fills *p with the reference defaults. */
+void vrt_default_params(vrt_params *p);
+int vrt_set_params(vrt_ctx *ctx, const vrt_params *p);
+
+/* texels: the byte stream octree_texture() returns (4 bytes per texel, root
+ * header at texel 0), used_bytes its size, tex_dim = ceil(cbrt(texels)).
+ * The library copies and re-lays it out for the device; the caller keeps
+ * ownership. texels == NULL / used_bytes == 0 uploads an empty world. */
+int vrt_upload_octree(vrt_ctx *ctx, const uint8_t *texels, size_t used_bytes, uint32_t tex_dim);
+int vrt_get_scene_info(const vrt_ctx *ctx, vrt_scene_info *info);
+
+/* Column-major mat4 x2 + vec4, exactly the std140 Camera block (comp:17-21). */
+int vrt_set_camera(vrt_ctx *ctx, const float inv_projection[16], const float inv_view[16],
+                   const float camera_pos[4]);
+
+/* Synchronous whole-frame dispatch into HOST buffers:
+ *   out_rgba8   width*height*4 bytes  (image binding 0, rgba8; row 0 = bottom, v = -1)
+ *   out_id_dist width*height*2 int32  (image binding 3, rg32i = voxelID, dist)
+ * Either pointer may be NULL. Any width/height >= 1 is accepted. */
+int vrt_dispatch(vrt_ctx *ctx, int width, int height, int mode, uint8_t *out_rgba8, int32_t *out_id_dist);
+
+/* Stream-ordered dispatch into DEVICE buffers laid out as full frames; only
+ * rows [row_begin, row_end) are traced and written (row sharding across GPUs).
+ * stream: a hipStream_t, or NULL for the context's own stream. Returns after
+ * enqueueing. */
+int vrt_dispatch_rows(vrt_ctx *ctx, int width, int height, int row_begin, int row_end, int mode,
+                      void *d_rgba8, void *d_id_dist, void *stream);
+
+/* Interleaved row-tile sharding: the frame is cut into tiles of tile_rows rows;
+ * shard s of n_shards owns tiles t with t % n_shards == s. Output buffers are
+ * COMPACT: the shard's tiles back to back in tile order (each W*tile_rows
+ * pixels, the last one possibly shorter). */
+int vrt_dispatch_shard(vrt_ctx *ctx, int width, int height, int tile_rows, int shard, int n_shards, int mode,
+                       void *d_rgba8, void *d_id_dist, void *stream);
+/* rows (and pixels = rows*width) a shard owns under that scheme */
+int vrt_shard_rows(int height, int tile_rows, int shard, int n_shards);
+
+/* Repeats vrt_dispatch_rows `iters` times on `stream` with a hipEvent pair
+ * around every launch and returns each launch's duration (ms) in ms_out[iters].
+ * Blocks until done. */
+int vrt_dispatch_timed(vrt_ctx *ctx, int width, int height, int row_begin, int row_end, int mode,
+                       void *d_rgba8, void *d_id_dist, void *stream, int iters, float *ms_out);
+
+/* Per-launch timing of the dispatches that follow: a hipEvent pair is recorded
+ * around each kernel launch, on the stream it is launched on, for up to
+ * max_launches launches (0 switches it off). vrt_profile_read waits for the
+ * recorded launches, writes their durations (ms) and returns how many. */
+int vrt_set_profiling(vrt_ctx *ctx, int max_launches);
+int vrt_profile_read(vrt_ctx *ctx, float *ms_out, int cap);
+
+int vrt_synchronize(vrt_ctx *ctx);
+/* the context's own stream (hipStream_t) and device ordinal */
+void *vrt_stream(vrt_ctx *ctx);
+int vrt_device(const vrt_ctx *ctx);
+
+/* kernel variant selection for A/B measurement (0 = default) */
+int vrt_set_variant(vrt_ctx *ctx, int variant);
+
+const char *vrt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

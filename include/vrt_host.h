@@ -1,0 +1,73 @@
+/*
+ * vrt_host.h -- C-ABI over the host-side library (libvrt_host.so) for callers
+ * that cannot include the C++ headers (ctypes / cgo / JNI style bindings).
+ * It wraps, without adding behaviour, the kept host API of the reference:
+ *   octree.hpp   (reference include/octree.hpp:22-30, src/octree.cpp)
+ *   voxReader.hpp(reference include/voxReader.hpp:14, src/voxReader.cpp)
+ *   Camera.hpp   (reference include/Camera.hpp:18-98; UBO math src/main.cpp:808-813)
+ * plus a .vox writer and the deterministic synthetic scenes used by the
+ * benchmark configurations whose inputs the reference does not ship.
+ * All functions are plain C, return 0/positive on success and negative on error
+ * unless stated otherwise.
+ */
+#ifndef VRT_HOST_H
+#define VRT_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vrth_world vrth_world; /* owns one octree root */
+
+/* root AABB [min,max); NULL/NULL = the reference's chunk (-1023)^3 .. (1024)^3 (src/main.cpp:478-480) */
+vrth_world *vrth_world_create(const int32_t *min3, const int32_t *max3);
+void vrth_world_destroy(vrth_world *w);
+void *vrth_world_root(vrth_world *w); /* Octree* for C++ callers */
+
+/* load_vox_file / in-memory variant: returns 1 or 0 like the reference's bool */
+int vrth_world_load_vox(vrth_world *w, const char *path, int ox, int oy, int oz);
+int vrth_world_load_vox_mem(vrth_world *w, const uint8_t *data, size_t len, int ox, int oy, int oz, long *inserted);
+
+/* octree_insert(VoxelObjCreate({refraction, illumination, k}, rgba, {x,y,z})) */
+int vrth_world_insert(vrth_world *w, int x, int y, int z, uint32_t rgba, float refraction, float illumination, float k);
+int vrth_world_insert_many(vrth_world *w, const int32_t *xyz, const uint32_t *rgba, size_t n, float refraction,
+                           float illumination, float k);
+int vrth_world_remove(vrth_world *w, int x, int y, int z);
+/* octree_find: out7 = {coord.x, coord.y, coord.z, color, refraction bits, illumination bits, k bits} */
+int vrth_world_find(vrth_world *w, int x, int y, int z, uint32_t out7[7]);
+/* octree_ray_cast with box (0,0,0)-(1024,1024,1024) as the reference passes (src/main.cpp:827):
+ * returns 1 and the hit node's voxel coord/has_voxel, 0 on miss */
+int vrth_world_ray_cast(vrth_world *w, const float origin[3], const float dir[3], int32_t hit_coord[3], int *has_voxel);
+
+size_t vrth_world_texel_count(vrth_world *w); /* _octree_texel_size */
+/* updateGPUTexture's host half (src/main.cpp:264-271): texel stream + tex_dim.
+ * *texels is malloc'd (release with vrth_free); empty world -> NULL, 0, dim 1 */
+int vrth_world_flatten(vrth_world *w, uint8_t **texels, size_t *bytes, uint32_t *tex_dim);
+void vrth_free(void *p);
+
+/* Camera(position, up=(0,1,0), yaw, pitch) -> the dispatch's Camera block for a width x height frame;
+ * front3 (optional) receives Camera::Front */
+int vrth_camera_block(const float pos[3], float yaw, float pitch, int width, int height, float inv_projection[16],
+                      float inv_view[16], float camera_pos[4], float *front3);
+
+/* MagicaVoxel writer (version 150: SIZE, XYZI, RGBA): xyzi = n * {x,y,z,colorIndex}, palette = 256 * {r,g,b,a} */
+int vrth_write_vox(const char *path, int sx, int sy, int sz, const uint8_t *xyzi, size_t n, const uint8_t *palette_rgba);
+/* same bytes into a malloc'd buffer (vrth_free) */
+int vrth_encode_vox(int sx, int sy, int sz, const uint8_t *xyzi, size_t n, const uint8_t *palette_rgba, uint8_t **out,
+                    size_t *out_len);
+
+/* deterministic synthetic scenes:
+ *  config 1 "custom.vox" stand-in: 64^3 model, floor slab + sphere -> malloc'd .vox bytes */
+int vrth_make_custom_vox(uint8_t **out, size_t *out_len);
+/*  config 4 procedural terrain inserted straight into the world (size x size columns) */
+int vrth_world_fill_terrain(vrth_world *w, int size, int seed);
+
+uint64_t vrth_fnv1a64(const uint8_t *p, size_t n);
+const char *vrth_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

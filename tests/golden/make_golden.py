@@ -1,0 +1,72 @@
+"""Regenerates the committed golden fixtures (run in the build container).
+
+  flatten.json : texel counts / tex_dim / FNV-1a-64 of octree_texture() for the three shipped maps.
+                 The hashes are the ones SURVEY.md 8(c) recorded from the reference's own host code;
+                 this script re-derives them with the oracle and refuses to write on a mismatch.
+  camera.json  : written by oracle/_ref/ref_camera (reference Camera.hpp + glm), see oracle/Makefile.
+  frames.json  : per-configuration outputs of the CPU restatement of raytracing.comp: FNV-1a-64 of the
+                 RGBA8 and RG32I images, hit counts and the exact texel-fetch count F that defines the
+                 algorithmic byte count B_algo = 4*F + 12*W*H.
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import oracle_py as O  # noqa: E402
+
+SURVEY_HASHES = {"dragon": "2de7c1f93b4b006c", "monu9": "dcbfa0413ceb4e8f", "nature": "41d4046e9b028993"}
+
+# (name, map, W, H, pose(x,y,z,yaw,pitch), modes)
+FRAMES = [
+    ("dragon_1080p", "dragon", 1920, 1080, (63.5, 60.5, 140.5, -90.0, -10.0), (0, 1)),
+    ("dragon_default_720p", "dragon", 1280, 720, (34.0, 60.0, 34.0, -90.0, 0.0), (0,)),
+    ("monu9_720p", "monu9", 1280, 720, (48.5, 60.5, 170.5, -90.0, -12.0), (0, 1)),
+    ("nature_4k", "nature", 3840, 2160, (60.5, 80.5, 200.5, -90.0, -20.0), (1,)),
+    ("dragon_256x144", "dragon", 256, 144, (63.5, 60.5, 140.5, -90.0, -10.0), (0, 1)),
+    ("monu9_192x108", "monu9", 192, 108, (48.5, 60.5, 170.5, -90.0, -12.0), (0, 1)),
+    ("nature_200x112", "nature", 200, 112, (60.5, 80.5, 200.5, -90.0, -20.0), (0, 1)),
+    ("dragon_inside_101x67", "dragon", 101, 67, (60.3, 30.7, 25.2, 37.0, 12.0), (0, 1)),
+]
+
+
+def main():
+    flat = {}
+    scenes = {}
+    for name, want in SURVEY_HASHES.items():
+        tree, ok, n = O.load_vox(os.path.join(HERE, "maps", name + ".vox"))
+        tex, dim = O.flatten(tree)
+        h = "%016x" % O.fnv1a64(tex)
+        if h != want:
+            raise SystemExit(f"{name}: oracle flatten hash {h} != recorded {want}")
+        flat[name] = {"voxels_inserted": n, "texels": tex.size // 4, "bytes": int(tex.size), "tex_dim": dim,
+                      "fnv1a64": h}
+        scenes[name] = (tex, dim)
+    json.dump({"source": "SURVEY.md 8(c) (reference host code); re-derived by oracle/", "maps": flat},
+              open(os.path.join(HERE, "flatten.json"), "w"), indent=1)
+
+    frames = {}
+    for name, m, W, H, pose, modes in FRAMES:
+        tex, dim = scenes[m]
+        (ip, iv, cp), _ = O.camera_ubo(pose[:3], pose[3], pose[4], W, H)
+        s = O.make_scene(tex, dim, ip, iv, cp)
+        for mode in modes:
+            rgba, idd, fm, st = O.render(s, W, H, mode, want_fetch_map=name.endswith('1080p'))
+            frames[f"{name}/mode{mode}"] = {
+                "map": m, "width": W, "height": H, "pose": list(pose), "mode": mode,
+                "rgba_fnv1a64": "%016x" % O.fnv1a64(rgba), "id_dist_fnv1a64": "%016x" % O.fnv1a64(idd),
+                "hits": st["hits"], "fetches": st["fetches"], "finds": st["finds"], "steps": st["steps"],
+                "root_restarts": st["root_restarts"], "shadow_rays": st["shadow_rays"],
+                "b_algo_bytes": 4 * st["fetches"] + 12 * W * H,
+            }
+            if fm is not None:  # per-row fetch totals: exact B_algo of any row shard of the bench frame
+                frames[f"{name}/mode{mode}"]["row_fetches"] = [int(v) for v in fm.sum(axis=1)]
+            print(name, mode, frames[f"{name}/mode{mode}"]["rgba_fnv1a64"], st["fetches"] / (W * H))
+    json.dump({"source": "oracle/rt_oracle.c (CPU restatement of raytracing.comp; shader parity unpinned)",
+               "frames": frames}, open(os.path.join(HERE, "frames.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

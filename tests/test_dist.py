@@ -1,0 +1,60 @@
+"""The N>1 path on CPU: two gloo ranks shard a frame by interleaved row tiles and gather it to rank 0.
+
+The device kernel cannot run here, so each rank fills its compact shard buffer from the oracle's rows
+(test infrastructure standing in for the GPU); what is under test is the product's sharding plan and
+the gather/un-interleave code that bench.py runs over RCCL."""
+import os
+import subprocess
+import sys
+import textwrap
+
+from conftest import ROOT
+
+WORKER = textwrap.dedent("""
+    import os, sys, importlib
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "oracle"))
+    import vrt_import, oracle_py as O
+    V = vrt_import.vrt()
+    shd = importlib.import_module("voxel-raytracer_amd.sharding")
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w = V.World(); assert w.load_vox(os.path.join({root!r}, "tests/golden/maps/monu9.vox"))
+    tex, dim = w.flatten()
+    for (W, H, tile_rows) in [(96, 54, 8), (64, 37, 5), (32, 8, 8)]:
+        ip, iv, cp, _ = V.camera_block((48.5, 60.5, 170.5), -90.0, -12.0, W, H)
+        s = O.make_scene(tex, dim, ip, iv, cp)
+        full_rgba, full_id, _, _ = O.render(s, W, H, 1)
+        plan = shd.ShardPlan(W, H, tile_rows, rank, world)
+        assert plan.rows_of[rank] == V.shard_row_indices(H, tile_rows, rank, world)
+        assert plan.rows_local == V.shard_rows(H, tile_rows, rank, world)
+        assert sorted(r for rows in plan.rows_of for r in rows) == list(range(H))
+        local = plan.local_buffer("cpu")
+        rows = plan.rows_of[rank]
+        if rows:
+            rm = plan.rows_max
+            local[: rm * W].view(rm, W)[: len(rows)] = torch.from_numpy(full_rgba[rows].copy().view(np.int32).reshape(len(rows), W))
+            local[rm * W:].view(rm, W, 2)[: len(rows)] = torch.from_numpy(full_id[rows].copy())
+        gathered = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
+        frame_rgba = torch.zeros((H, W), dtype=torch.int32) if rank == 0 else None
+        frame_id = torch.zeros((H, W, 2), dtype=torch.int32) if rank == 0 else None
+        idx = plan.frame_index("cpu") if rank == 0 else None
+        shd.gather_frame(plan, local, gathered, frame_rgba, frame_id, idx)
+        if rank == 0:
+            assert np.array_equal(frame_rgba.numpy().view(np.uint8).reshape(H, W, 4), full_rgba)
+            assert np.array_equal(frame_id.numpy(), full_id)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_two_rank_gloo_shard_and_gather(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout

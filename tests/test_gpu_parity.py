@@ -1,0 +1,225 @@
+"""Parity of the gfx950 kernels (through the C-ABI) against the CPU oracle and the committed golden frames.
+
+Bit-exact bar: RGBA8 and RG32I outputs must be identical, pixel for pixel."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import MAPS
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = list(range(10))
+
+
+@pytest.fixture(scope="module")
+def ctx(V):
+    c = V.Context(0)
+    yield c
+    c.close()
+
+
+def _setup(ctx, V, tex, dim, pose, W, H, highlighted=None):
+    ip, iv, cp, _ = V.camera_block(pose[:3], pose[3], pose[4], W, H)
+    ctx.upload_octree(tex, dim)
+    ctx.set_camera(ip, iv, cp)
+    p = ctx.default_params()
+    if highlighted is not None:
+        p.highlighted[:] = highlighted
+    ctx.set_params(p)
+    return ip, iv, cp
+
+
+def _oracle_frame(O, tex, dim, cam, W, H, mode, highlighted=(-1, -1, -1)):
+    s = O.make_scene(tex, dim, *cam, highlighted=highlighted)
+    rgba, idd, _, st = O.render(s, W, H, mode)
+    return rgba, idd, st
+
+
+def _assert_same(got, ref, what):
+    if not np.array_equal(got, ref):
+        bad = np.argwhere(np.any(got != ref, axis=-1))
+        y, x = bad[0]
+        raise AssertionError(f"{what}: {len(bad)} pixels differ; first at (x={x}, y={y}): got {got[y, x]} want {ref[y, x]}")
+
+
+def test_arithmetic_contract_on_device(ctx):
+    """'/', sqrt, floor, rint are correctly rounded and a*b+c is not fused: compared with numpy float32."""
+    rng = np.random.default_rng(0)
+    n = 1 << 16
+    a = np.concatenate([rng.normal(size=n // 2) * 10.0 ** rng.integers(-30, 30, size=n // 2),
+                        rng.uniform(-1100, 1100, size=n // 2)]).astype(np.float32)
+    b = np.concatenate([rng.normal(size=n // 2) * 10.0 ** rng.integers(-30, 30, size=n // 2),
+                        rng.uniform(-3, 3, size=n // 2)]).astype(np.float32)
+    b[b == 0] = 1.0
+    with np.errstate(all="ignore"):
+        assert np.array_equal(ctx.debug_math(0, a, b).view(np.uint32), (a / b).astype(np.float32).view(np.uint32))
+        pa = np.abs(a)
+        assert np.array_equal(ctx.debug_math(1, pa, b).view(np.uint32), np.sqrt(pa).view(np.uint32))
+        assert np.array_equal(ctx.debug_math(2, pa + np.float32(1e-30), b).view(np.uint32),
+                              (np.float32(1.0) / np.sqrt(pa + np.float32(1e-30))).view(np.uint32))
+        assert np.array_equal(ctx.debug_math(3, a, b).view(np.uint32), np.floor(a).view(np.uint32))
+        assert np.array_equal(ctx.debug_math(4, a, b).view(np.uint32), np.rint(a).view(np.uint32))
+        prod = (a * b).astype(np.float32)
+        assert np.array_equal(ctx.debug_math(5, a, b).view(np.uint32), (prod + np.float32(1.0)).view(np.uint32))
+        assert np.array_equal(ctx.debug_math(8, a, b).view(np.uint32), (a + b).view(np.uint32))
+        assert np.array_equal(ctx.debug_math(9, a, b).view(np.uint32), prod.view(np.uint32))
+
+
+def test_det_exp_matches_oracle(ctx, O):
+    x = np.linspace(-90, 89, 20001).astype(np.float32)
+    got = ctx.debug_math(6, x, x)
+    ref = np.array([O.lib().o_det_expf(float(v)) for v in x], np.float32)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("key", ["dragon_256x144/mode0", "dragon_256x144/mode1", "monu9_192x108/mode0",
+                                 "monu9_192x108/mode1", "nature_200x112/mode0", "nature_200x112/mode1",
+                                 "dragon_inside_101x67/mode0", "dragon_inside_101x67/mode1"])
+def test_small_frames_vs_oracle_and_golden(ctx, V, O, golden, product_scenes, key):
+    g = golden["frames"]["frames"][key]
+    tex, dim = product_scenes[g["map"]]
+    W, H = g["width"], g["height"]
+    cam = _setup(ctx, V, tex, dim, g["pose"], W, H)
+    ref_rgba, ref_id, _ = _oracle_frame(O, tex, dim, cam, W, H, g["mode"])
+    for v in VARIANTS:
+        ctx.set_variant(v)
+        rgba, idd = ctx.dispatch(W, H, g["mode"])
+        _assert_same(rgba, ref_rgba, f"{key} variant {v} rgba8")
+        _assert_same(idd, ref_id, f"{key} variant {v} id/dist")
+        assert "%016x" % V.fnv1a64(rgba) == g["rgba_fnv1a64"]
+        assert "%016x" % V.fnv1a64(idd) == g["id_dist_fnv1a64"]
+    ctx.set_variant(0)
+
+
+@pytest.mark.parametrize("key", ["dragon_1080p/mode0", "dragon_1080p/mode1", "monu9_720p/mode0", "monu9_720p/mode1",
+                                 "dragon_default_720p/mode0", "nature_4k/mode1"])
+def test_full_size_frames_match_committed_hashes(ctx, V, golden, product_scenes, key):
+    """BASELINE.json sizes: the oracle's frame hashes were committed by tests/golden/make_golden.py."""
+    g = golden["frames"]["frames"][key]
+    tex, dim = product_scenes[g["map"]]
+    W, H = g["width"], g["height"]
+    _setup(ctx, V, tex, dim, g["pose"], W, H)
+    rgba, idd = ctx.dispatch(W, H, g["mode"])
+    assert "%016x" % V.fnv1a64(rgba) == g["rgba_fnv1a64"], key
+    assert "%016x" % V.fnv1a64(idd) == g["id_dist_fnv1a64"], key
+    hits = int(np.count_nonzero(idd[..., 0]))
+    assert hits <= g["hits"] and hits >= g["hits"] - 4  # voxelID 0 is also a legal id for the voxel at the origin
+
+
+def test_degenerate_inputs(ctx, V, O, product_scenes):
+    tex, dim = product_scenes["dragon"]
+    # F8: camera exactly on voxel boundaries, axis-aligned middle row/column (zero-length steps until the cap)
+    for pose, (W, H) in [((34.0, 60.0, 34.0, -90.0, 0.0), (64, 36)), ((20.0, 30.0, 20.0, 0.0, 0.0), (40, 40)),
+                         ((63.5, 2000.0, 30.5, -90.0, -89.0), (32, 32)),   # camera outside the world (above)
+                         ((-2000.5, 50.5, 30.5, 0.0, 0.0), (32, 18)),      # outside, looking in along +x
+                         ((63.5, 60.5, 140.5, -90.0, -10.0), (1, 1)), ((63.5, 60.5, 140.5, -90.0, -10.0), (13, 7))]:
+        cam = _setup(ctx, V, tex, dim, pose, W, H)
+        for mode in (0, 1):
+            ref_rgba, ref_id, _ = _oracle_frame(O, tex, dim, cam, W, H, mode)
+            rgba, idd = ctx.dispatch(W, H, mode)
+            _assert_same(rgba, ref_rgba, f"pose {pose} {W}x{H} mode {mode} rgba8")
+            _assert_same(idd, ref_id, f"pose {pose} {W}x{H} mode {mode} id/dist")
+    # empty world: every pixel is sky
+    cam = _setup(ctx, V, np.zeros(0, np.uint8), 1, (10.5, 10.5, 10.5, -90.0, 0.0), 48, 24)
+    ref_rgba, ref_id, _ = _oracle_frame(O, np.zeros(0, np.uint8), 1, cam, 48, 24, 1)
+    rgba, idd = ctx.dispatch(48, 24, 1)
+    _assert_same(rgba, ref_rgba, "empty world rgba8")
+    _assert_same(idd, ref_id, "empty world id/dist")
+    assert np.all(idd[..., 0] == 0) and np.all(idd[..., 1] == 2047)
+
+
+def test_materials_highlight_and_translucent_fallback(ctx, V, O):
+    """Emissive, translucent and highlighted voxels + a camera sitting inside a translucent medium."""
+    w = V.World()
+    rng = np.random.default_rng(5)
+    for x in range(0, 24):
+        for z in range(0, 24):
+            w.insert(x, 0, z, 0xa0a0a0ff)                       # stone floor
+    for _ in range(200):
+        x, y, z = (int(v) for v in rng.integers(2, 22, size=3))
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            w.insert(x, y, z, 0xffd2d2ff, 3.0, 1.0, 0.0)        # light
+        elif kind == 1:
+            w.insert(x, y, z, 0x3c64dc96, 1.33, 0.0, 0.0)       # water (alpha 150)
+        elif kind == 2:
+            w.insert(x, y, z, 0xc8dcff50, 1.5, 0.0, 0.0)        # glass
+        else:
+            w.insert(x, y, z, 0x50b43cff)                       # grass
+    for x in range(30, 36):
+        for y in range(2, 8):
+            for z in range(8, 14):
+                w.insert(x, y, z, 0x3c64dc96, 1.33, 0.0, 0.0)   # a block of water to put the camera in
+    tex, dim = w.flatten()
+    for pose, hl in [((12.3, 14.2, 40.7, -90.0, -15.0), (-1, -1, -1)), ((12.3, 14.2, 40.7, -90.0, -15.0), (5, 0, 20)),
+                     ((32.5, 4.5, 10.5, 180.0, 5.0), (-1, -1, -1))]:
+        W, H = 96, 64
+        cam = _setup(ctx, V, tex, dim, pose, W, H, highlighted=hl)
+        for mode in (0, 1):
+            ref_rgba, ref_id, _ = _oracle_frame(O, tex, dim, cam, W, H, mode, highlighted=hl)
+            rgba, idd = ctx.dispatch(W, H, mode)
+            _assert_same(rgba, ref_rgba, f"materials pose {pose} hl {hl} mode {mode} rgba8")
+            _assert_same(idd, ref_id, f"materials pose {pose} hl {hl} mode {mode} id/dist")
+
+
+def test_row_sharding_properties_at_full_size(ctx, V, golden, product_scenes):
+    """N-shard result == 1-GPU result byte for byte (virtual shards on one device), at 1920x1080."""
+    import torch
+    g = golden["frames"]["frames"]["dragon_1080p/mode1"]
+    tex, dim = product_scenes["dragon"]
+    W, H = g["width"], g["height"]
+    _setup(ctx, V, tex, dim, g["pose"], W, H)
+    full_rgba, full_id = ctx.dispatch(W, H, 1)
+    assert "%016x" % V.fnv1a64(full_rgba) == g["rgba_fnv1a64"]
+    dev = torch.device("cuda:0")
+    # contiguous row blocks written in place
+    d_rgba = torch.zeros((H, W), dtype=torch.int32, device=dev)
+    d_id = torch.zeros((H, W, 2), dtype=torch.int32, device=dev)
+    for r0, r1 in [(0, 135), (135, 541), (541, 1079), (1079, 1080)]:
+        ctx.dispatch_rows(W, H, r0, r1, 1, d_rgba.data_ptr(), d_id.data_ptr())
+    ctx.synchronize()
+    assert np.array_equal(d_rgba.cpu().numpy().view(np.uint8).reshape(H, W, 4), full_rgba)
+    assert np.array_equal(d_id.cpu().numpy(), full_id)
+    # interleaved 8-row tiles, compact shard buffers, 8 shards (and a ragged 3-shard / 5-row-tile split)
+    for tile_rows, n_shards in [(8, 8), (5, 3), (1080, 2)]:
+        out_rgba = np.zeros_like(full_rgba)
+        out_id = np.zeros_like(full_id)
+        for s in range(n_shards):
+            rows = V.shard_row_indices(H, tile_rows, s, n_shards)
+            assert len(rows) == V.shard_rows(H, tile_rows, s, n_shards)
+            if not rows:
+                continue
+            sr = torch.zeros((len(rows), W), dtype=torch.int32, device=dev)
+            si = torch.zeros((len(rows), W, 2), dtype=torch.int32, device=dev)
+            ctx.dispatch_shard(W, H, tile_rows, s, n_shards, 1, sr.data_ptr(), si.data_ptr())
+            ctx.synchronize()
+            out_rgba[rows] = sr.cpu().numpy().view(np.uint8).reshape(len(rows), W, 4)
+            out_id[rows] = si.cpu().numpy()
+        assert np.array_equal(out_rgba, full_rgba) and np.array_equal(out_id, full_id), (tile_rows, n_shards)
+    # idempotence: a second dispatch of the same frame is identical
+    again_rgba, again_id = ctx.dispatch(W, H, 1)
+    assert np.array_equal(again_rgba, full_rgba) and np.array_equal(again_id, full_id)
+
+
+def test_error_behaviour(V):
+    c = V.Context(0)
+    with pytest.raises(V.VrtError, match="no octree"):
+        c.dispatch(8, 8, 0)
+    c.upload_octree(np.zeros(0, np.uint8), 1)
+    with pytest.raises(V.VrtError, match="no camera"):
+        c.dispatch(8, 8, 0)
+    ip, iv, cp, _ = V.camera_block((1.5, 2.5, 3.5), -90.0, 0.0, 8, 8)
+    c.set_camera(ip, iv, cp)
+    with pytest.raises(V.VrtError):
+        c.dispatch(0, 8, 0)
+    with pytest.raises(V.VrtError):
+        c.dispatch(8, 8, 7)
+    with pytest.raises(V.VrtError, match="multiple of 4"):
+        c.upload_octree(np.zeros(7, np.uint8), 1)
+    # a self-referencing header is rejected instead of being expanded forever
+    cyc = np.array([1, 0, 0, 0xff] + [0, 0, 0, 0] * 8, np.uint8)
+    with pytest.raises(V.VrtError, match="record limit"):
+        c.upload_octree(cyc, 3)
+    c.close()

@@ -1,0 +1,243 @@
+"""The product host library (octree.hpp / voxReader.hpp / Camera.hpp API) against golden vectors and the oracle (CPU)."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import MAPS, random_voxels
+
+
+def _f(u):
+    return struct.unpack("f", struct.pack("I", u))[0]
+
+
+def test_flatten_is_byte_identical_to_reference_hashes(V, golden, product_scenes):
+    for name, g in golden["flatten"]["maps"].items():
+        tex, dim = product_scenes[name]
+        assert tex.size == g["bytes"] and dim == g["tex_dim"]
+        assert "%016x" % V.fnv1a64(tex) == g["fnv1a64"]
+
+
+def test_camera_block_bits(V, golden):
+    for c in golden["camera"]["cases"]:
+        ip, iv, cp, fr = V.camera_block([_f(x) for x in c["pos"]], _f(c["yaw"]), _f(c["pitch"]), c["width"], c["height"])
+        assert list(ip.view(np.uint32)) == c["inv_proj"]
+        assert list(iv.view(np.uint32)) == c["inv_view"]
+        assert list(fr.view(np.uint32)) == c["front"]
+        assert list(cp.view(np.uint32)) == c["pos"] + [0x3f800000]
+    p = V.Params()
+    V.hip_lib().vrt_default_params(C.byref(p))
+    assert list(np.array(p.light_dir, np.float32).view(np.uint32)) == golden["camera"]["light_dir"]
+
+
+def _oracle_tree_from(O, xyz, rgba):
+    L = O.lib()
+    t = O.new_tree()
+    for (x, y, z), c in zip(xyz, rgba):
+        L.o_octree_insert(t, O.VoxelObj(O.IVec3(int(x), int(y), int(z)), int(c), O.Voxel(3.0, 0.0, 0.0)))
+    return t
+
+
+@pytest.mark.parametrize("seed,n,lo,hi", [(1, 1, 0, 50), (2, 500, 0, 24), (3, 4000, -40, 40), (4, 3000, -1023, 1024),
+                                          (5, 6000, 0, 16), (6, 2500, 1000, 1024)])
+def test_random_builds_flatten_like_the_oracle(V, O, seed, n, lo, hi):
+    """Insert (with heavy overlap so merges/re-splits happen), then remove a subset: bytes must match at each stage."""
+    rng = np.random.default_rng(seed)
+    xyz, rgba = random_voxels(rng, n, lo, hi, n_colors=2 if seed == 5 else 5)
+    w = V.World()
+    w.insert_many(xyz, rgba)
+    t = _oracle_tree_from(O, xyz, rgba)
+    a, da = w.flatten()
+    b, db = O.flatten(t)
+    assert da == db and np.array_equal(a, b)
+    assert w.texel_count() == O.lib().o_octree_texel_size(t)
+    for i in rng.permutation(n)[: n // 3]:
+        x, y, z = (int(v) for v in xyz[i])
+        w.remove(x, y, z)
+        O.lib().o_octree_remove(t, O.IVec3(x, y, z))
+    a, da = w.flatten()
+    b, db = O.flatten(t)
+    assert da == db and np.array_equal(a, b)
+    # re-insert over the holes with one material: exercises merge-up
+    w.insert_many(xyz[: n // 2], np.full(n // 2, 0x808080ff, np.uint32))
+    for x, y, z in xyz[: n // 2]:
+        O.lib().o_octree_insert(t, O.VoxelObj(O.IVec3(int(x), int(y), int(z)), 0x808080ff, O.Voxel(3.0, 0.0, 0.0)))
+    a, da = w.flatten()
+    b, db = O.flatten(t)
+    assert da == db and np.array_equal(a, b)
+    # octree_find parity (including the y-blind equality of the shipped vmm)
+    for x, y, z in rng.integers(lo - 2, hi + 2, size=(300, 3)):
+        got = w.find(int(x), int(y), int(z))
+        ref = O.lib().o_octree_find(t, O.IVec3(int(x), int(y), int(z)))
+        assert got["coord"] == (ref.coord.x, ref.coord.y, ref.coord.z) and got["color"] == ref.color
+    O.lib().o_octree_delete(t)
+    w.close()
+
+
+def test_solid_block_merges_to_one_leaf(V):
+    w = V.World(world_min=(0, 0, 0), world_max=(8, 8, 8))
+    pts = np.array([(x, y, z) for x in range(8) for y in range(8) for z in range(8)], np.int32)
+    w.insert_many(pts, np.full(len(pts), 0x102030ff, np.uint32))
+    # everything merged into the root: a lone leaf root flattens to its 2 data texels
+    tex, dim = w.flatten()
+    assert w.texel_count() == 2 and tex.size == 8 and list(tex[:4]) == [0x10, 0x20, 0x30, 255] and tex[4] == 255
+    w.remove(3, 3, 3)
+    assert w.texel_count() > 2
+
+
+def test_empty_world(V):
+    w = V.World()
+    tex, dim = w.flatten()
+    assert tex.size == 0 and dim == 1 and w.texel_count() == 0
+    assert w.ray_cast((0.5, 0.5, 0.5), (0.0, 0.0, -1.0)) is None
+    rec, info = V.build_layout(tex)
+    assert info.n_records == 1 and rec[0, 0] == 0
+
+
+def test_vox_loader_raw_and_errors(V, O, tmp_path):
+    data = V.make_custom_vox()
+    w = V.World()
+    ok, n = w.load_vox_bytes(data)
+    t, ok2, n2 = O.load_vox(data)
+    assert ok and ok2 and n == n2 and n > 10000
+    a, da = w.flatten()
+    b, db = O.flatten(t)
+    assert da == db and np.array_equal(a, b)
+    # through a file as well
+    p = tmp_path / "custom.vox"
+    p.write_bytes(data)
+    w2 = V.World()
+    assert w2.load_vox(p)
+    assert np.array_equal(w2.flatten()[0], a)
+    # error behaviour of load_vox_file: missing file, bad magic, no voxels -> false
+    assert not V.World().load_vox(tmp_path / "nope.vox")
+    bad = tmp_path / "bad.vox"
+    bad.write_bytes(b"NOPE" + data[4:])
+    assert not V.World().load_vox(bad)
+    empty = V.encode_vox((4, 4, 4), np.zeros((0, 4), np.uint8))
+    assert V.World().load_vox_bytes(empty + b"\0" * 16)[0] is False
+    # truncated file: whatever was parsed before the cut is still what both sides build
+    cut = data[: len(data) // 2]
+    wa = V.World()
+    oka, na = wa.load_vox_bytes(cut)
+    tb, okb, nb = O.load_vox(cut)
+    assert oka == okb and na == nb and np.array_equal(wa.flatten()[0], O.flatten(tb)[0])
+
+
+def _chunk(tag, content, children=b""):
+    return tag + struct.pack("<ii", len(content), len(children)) + content + children
+
+
+def _vstr(s):
+    return struct.pack("<i", len(s)) + s
+
+
+def _vdict(d):
+    out = struct.pack("<i", len(d))
+    for k, v in d.items():
+        out += _vstr(k) + _vstr(v)
+    return out
+
+
+def _scene_graph_vox(rot_byte, translation, second_translation):
+    """Two 3x2x4 models placed by nTRN/nGRP/nSHP nodes (the chunk grammar MagicaVoxel writes)."""
+    def model(seed):
+        rng = np.random.default_rng(seed)
+        pts = [(x, y, z, 1 + int(rng.integers(0, 200))) for x in range(3) for y in range(2) for z in range(4)
+               if rng.random() < 0.8]
+        return _chunk(b"SIZE", struct.pack("<iii", 3, 2, 4)) + \
+            _chunk(b"XYZI", struct.pack("<i", len(pts)) + bytes(v for p in pts for v in p))
+    body = model(1) + model(2)
+    trn = lambda nid, child, frame: _chunk(b"nTRN", struct.pack("<i", nid) + _vdict({}) +
+                                           struct.pack("<iiii", child, -1, 0, 1) + _vdict(frame))
+    body += trn(0, 1, {})
+    body += _chunk(b"nGRP", struct.pack("<i", 1) + _vdict({}) + struct.pack("<iii", 2, 2, 4))
+    body += trn(2, 3, {b"_t": translation, b"_r": str(rot_byte).encode()})
+    body += _chunk(b"nSHP", struct.pack("<i", 3) + _vdict({}) + struct.pack("<i", 1) + struct.pack("<i", 0) + _vdict({}))
+    body += trn(4, 5, {b"_t": second_translation})
+    body += _chunk(b"nSHP", struct.pack("<i", 5) + _vdict({}) + struct.pack("<i", 1) + struct.pack("<i", 1) + _vdict({}))
+    pal = bytes((i, 255 - i, (i * 7) & 255, 255)[j] for i in range(256) for j in range(4))
+    body += _chunk(b"RGBA", pal)
+    return b"VOX " + struct.pack("<i", 150) + _chunk(b"MAIN", b"", body) + b"\0" * 12
+
+
+@pytest.mark.parametrize("rot", [4, 2, 9, 17, 40, 98, 120, 1, 6, 24, 70])
+def test_vox_loader_scene_graph_matches_oracle(V, O, rot):
+    data = _scene_graph_vox(rot, b"10 -7 5", b"-3 12 20")
+    w = V.World()
+    ok, _ = w.load_vox_bytes(data, offset=(100, 50, 60))
+    t, ok2, n2 = O.load_vox(data, offset=(100, 50, 60))
+    assert ok and ok2 and n2 > 20
+    a, da = w.flatten()
+    b, db = O.flatten(t)
+    assert a.size > 0 and da == db and np.array_equal(a, b)
+
+
+def test_cpu_ray_cast_matches_oracle_config1(V, O):
+    """BASELINE config 1: custom.vox stand-in, 256x256, single-thread octree_ray_cast per pixel (sampled here)."""
+    data = V.make_custom_vox()
+    w = V.World()
+    assert w.load_vox_bytes(data)[0]
+    t, _, _ = O.load_vox(data)
+    W = H = 256
+    ip, iv, cp, fr = V.camera_block((32.5, 40.5, 150.5), -90.0, -8.0, W, H)
+    # same worldDir the kernel would use: take it from the oracle's ray setup via a tiny frame render
+    rng = np.random.default_rng(3)
+    hits = 0
+    for _ in range(600):
+        o = (np.float32(32.5) + np.float32(rng.uniform(-20, 20)), np.float32(40.5) + np.float32(rng.uniform(-20, 20)),
+             np.float32(150.5))
+        target = rng.uniform(-10, 74, size=3)
+        d = (target - np.array(o, np.float64)).astype(np.float32)
+        d = d / np.float32(np.linalg.norm(d)) * np.float32(rng.uniform(0.5, 2.0))
+        got = w.ray_cast(o, d)
+        ref = O.lib().o_octree_ray_cast(t, O.Vec3(*[float(v) for v in o]), O.Vec3(*[float(v) for v in d]),
+                                        O.Vec3(0, 0, 0), O.Vec3(1024, 1024, 1024))
+        if ref:
+            hits += 1
+            n = ref.contents
+            assert got == ((n.voxel.coord.x, n.voxel.coord.y, n.voxel.coord.z), bool(n.has_voxel))
+        else:
+            assert got is None
+    assert hits > 100
+
+
+def test_layout_walk_equals_texel_walk(V, O, product_scenes):
+    """The device record array answers point queries exactly like the texel stream does."""
+    tex, dim = product_scenes["monu9"]
+    rec, info = V.build_layout(tex)
+    assert info.n_records == info.n_internal + info.n_leaves == rec.shape[0]
+    s = O.make_scene(tex, dim, np.eye(4, dtype=np.float32).ravel(), np.eye(4, dtype=np.float32).ravel(), [0, 0, 0, 1])
+    leaf = (C.c_uint8 * 8)()
+    mn, mx = (C.c_int32 * 3)(), (C.c_int32 * 3)()
+    rng = np.random.default_rng(11)
+    pts = np.concatenate([rng.integers(-10, 110, size=(3000, 3)), rng.integers(-1023, 1024, size=(500, 3))])
+    for p in pts:
+        found = O.lib().o_find_point(C.byref(s), (C.c_int32 * 3)(*[int(v) for v in p]), leaf, mn, mx)
+        lo, hi = [-1023] * 3, [1024] * 3
+        masks, base = int(rec[0, 0]), int(rec[0, 1])
+        got = None
+        for _ in range(16):
+            mid = [lo[i] + (hi[i] - lo[i]) // 2 for i in range(3)]
+            ci = (4 if p[0] >= mid[0] else 0) | (2 if p[1] >= mid[1] else 0) | (1 if p[2] >= mid[2] else 0)
+            for i, bit in enumerate((4, 2, 1)):
+                if ci & bit:
+                    lo[i] = mid[i]
+                else:
+                    hi[i] = mid[i]
+            if not (masks >> ci) & 1:
+                got = (0, None)
+                break
+            idx = base + bin(masks & 0xff & ((1 << ci) - 1)).count("1")
+            if (masks >> (8 + ci)) & 1:
+                got = (1, (int(rec[idx, 0]), int(rec[idx, 1])))
+                break
+            masks, base = int(rec[idx, 0]), int(rec[idx, 1])
+        assert got is not None and got[0] == found
+        assert lo == list(mn) and hi == list(mx)
+        if found:
+            w0, w1 = got[1]
+            assert (w0 & 0xff, (w0 >> 8) & 0xff, (w0 >> 16) & 0xff, w0 >> 24) == (leaf[0], leaf[1], leaf[2], leaf[7])
+            assert (w1 & 0xff, (w1 >> 8) & 0xff, (w1 >> 16) & 0xff) == (leaf[4], leaf[5], leaf[6])

@@ -1,0 +1,104 @@
+"""The oracle against the golden vectors (CPU)."""
+import os
+import struct
+
+import numpy as np
+
+from conftest import MAPS
+
+
+def _f(u):
+    return struct.unpack("f", struct.pack("I", u))[0]
+
+
+def test_flatten_matches_recorded_hashes(O, golden):
+    for name, g in golden["flatten"]["maps"].items():
+        tree, ok, n = O.load_vox(os.path.join(MAPS, name + ".vox"))
+        assert ok and n == g["voxels_inserted"]
+        tex, dim = O.flatten(tree)
+        assert tex.size == g["bytes"] and dim == g["tex_dim"]
+        assert "%016x" % O.fnv1a64(tex) == g["fnv1a64"]
+        # root header: pointer list right behind it
+        assert int(tex[0]) | int(tex[1]) << 8 | int(tex[2]) << 16 == 1
+        O.lib().o_octree_delete(tree)
+
+
+def test_camera_matches_reference_bits(O, golden):
+    for c in golden["camera"]["cases"]:
+        (ip, iv, cp), cam = O.camera_ubo([_f(x) for x in c["pos"]], _f(c["yaw"]), _f(c["pitch"]), c["width"], c["height"])
+        assert list(ip.view(np.uint32)) == c["inv_proj"]
+        assert list(iv.view(np.uint32)) == c["inv_view"]
+        assert list(np.array(cam.front, np.float32).view(np.uint32)) == c["front"]
+        assert list(np.array(cam.right, np.float32).view(np.uint32)) == c["right"]
+        assert list(np.array(cam.up, np.float32).view(np.uint32)) == c["up"]
+    s = O.Scene()
+    O.lib().o_scene_defaults(s)
+    assert list(np.array(s.light_dir, np.float32).view(np.uint32)) == golden["camera"]["light_dir"]
+
+
+def test_small_frames_match_committed_hashes(O, golden):
+    scenes = {}
+    for key, g in golden["frames"]["frames"].items():
+        if g["width"] * g["height"] > 64 * 1024:
+            continue
+        if g["map"] not in scenes:
+            tree, _, _ = O.load_vox(os.path.join(MAPS, g["map"] + ".vox"))
+            scenes[g["map"]] = O.flatten(tree)
+        tex, dim = scenes[g["map"]]
+        p = g["pose"]
+        (ip, iv, cp), _ = O.camera_ubo(p[:3], p[3], p[4], g["width"], g["height"])
+        rgba, idd, _, st = O.render(O.make_scene(tex, dim, ip, iv, cp), g["width"], g["height"], g["mode"])
+        assert "%016x" % O.fnv1a64(rgba) == g["rgba_fnv1a64"], key
+        assert "%016x" % O.fnv1a64(idd) == g["id_dist_fnv1a64"], key
+        assert st["fetches"] == g["fetches"] and st["hits"] == g["hits"], key
+
+
+def test_find_agrees_with_dense_grid(O):
+    """octreeFind restatement vs a brute-force dense occupancy grid built from the voxel list."""
+    rng = np.random.default_rng(7)
+    L = O.lib()
+    tree = O.new_tree()
+    n = 3000
+    xyz = rng.integers(0, 40, size=(n, 3))
+    cols = rng.integers(1, 4, size=n)
+    grid = {}
+    for (x, y, z), c in zip(xyz, cols):
+        color = (int(c) * 0x203040 << 8 | 0xff) & 0xffffffff
+        L.o_octree_insert(tree, O.VoxelObj(O.IVec3(int(x), int(y), int(z)), color, O.Voxel(3.0, 0.0, 0.0)))
+        grid[(int(x), int(y), int(z))] = color
+    tex, dim = O.flatten(tree)
+    s = O.make_scene(tex, dim, np.eye(4, dtype=np.float32).ravel(), np.eye(4, dtype=np.float32).ravel(), [0, 0, 0, 1])
+    import ctypes as C
+    leaf = (C.c_uint8 * 8)()
+    mn, mx = (C.c_int32 * 3)(), (C.c_int32 * 3)()
+    for _ in range(4000):
+        p = rng.integers(-3, 44, size=3)
+        found = L.o_find_point(C.byref(s), (C.c_int32 * 3)(*[int(v) for v in p]), leaf, mn, mx)
+        key = tuple(int(v) for v in p)
+        assert all(mn[i] <= key[i] < mx[i] for i in range(3))
+        if key in grid:
+            assert found == 1 and leaf[7] == 255
+            c = grid[key]
+            assert (leaf[0], leaf[1], leaf[2]) == ((c >> 24) & 255, (c >> 16) & 255, (c >> 8) & 255)
+        else:
+            # empty space or a phantom alpha-0 leaf: never an opaque voxel
+            assert found == 0 or leaf[7] == 0
+        # the node found must not contain any OTHER material: every cell of an opaque leaf is that voxel
+        if found == 1 and leaf[7] == 255:
+            ext = [mx[i] - mn[i] for i in range(3)]
+            if max(ext) <= 4:
+                for dx in range(ext[0]):
+                    for dy in range(ext[1]):
+                        for dz in range(ext[2]):
+                            assert (mn[0] + dx, mn[1] + dy, mn[2] + dz) in grid
+    L.o_octree_delete(tree)
+
+
+def test_det_math_is_sane(O):
+    L = O.lib()
+    xs = np.linspace(-20, 5, 101)
+    assert np.allclose([L.o_det_expf(float(x)) for x in xs], np.exp(xs), rtol=3e-7)
+    ts = np.linspace(0, 6.3, 97)
+    assert np.allclose([L.o_det_sinf(float(t)) for t in ts], np.sin(ts), atol=3e-7)
+    assert np.allclose([L.o_det_cosf(float(t)) for t in ts], np.cos(ts), atol=3e-7)
+    assert abs(L.o_det_powf(0.37, 5.0) - 0.37 ** 5) < 1e-8

@@ -1,0 +1,363 @@
+"""ctypes bindings over the two C-ABI libraries of the MI355X ray-casting path.
+
+    libvrt_host.so  (include/vrt_host.h)  host API kept from the reference:
+                    octree build/flatten, .vox loader, camera block
+    libvrt_hip.so   (include/vrt.h)       the gfx950 dispatch layer
+
+The directory name carries a hyphen, so import it with
+``importlib.import_module("voxel-raytracer_amd")`` (see ``vrt_import.py`` at the
+repository root). There is no CPU fallback anywhere in this package: `Context`
+raises if the HIP library is missing or no GPU is present.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+HIP_LIB = os.path.join(HERE, "libvrt_hip.so")
+HOST_LIB = os.path.join(HERE, "libvrt_host.so")
+
+MODE_PRIMARY, MODE_PRIMARY_SHADOW, MODE_FULL = 0, 1, 2
+MODES = {"primary": MODE_PRIMARY, "primary_shadow": MODE_PRIMARY_SHADOW, "full": MODE_FULL}
+
+
+class VrtError(RuntimeError):
+    pass
+
+
+def build(targets=("../libvrt_hip.so", "../libvrt_host.so")):
+    """Compile the libraries in-tree (hipcc --offload-arch=gfx950 / g++)."""
+    subprocess.check_call(["make", "-C", CSRC, *targets])
+
+
+class Params(C.Structure):
+    _fields_ = [("voxel_scale", C.c_float), ("world_min", C.c_int32 * 3), ("world_max", C.c_int32 * 3),
+                ("global_light", C.c_float * 4), ("light_dir", C.c_float * 3), ("highlighted", C.c_int32 * 3)]
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [("tex_dim", C.c_uint32), ("n_texels", C.c_uint32), ("n_records", C.c_uint32),
+                ("n_internal", C.c_uint32), ("n_leaves", C.c_uint32), ("max_depth", C.c_uint32),
+                ("lds_records", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+_host = None
+_hip = None
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB):
+            raise VrtError(f"{HOST_LIB} is missing: run __graft_entry__.build() (make -C {CSRC})")
+        L = C.CDLL(HOST_LIB)
+        L.vrth_world_create.restype = C.c_void_p
+        L.vrth_world_create.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.vrth_world_destroy.argtypes = [C.c_void_p]
+        L.vrth_world_load_vox.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
+        L.vrth_world_load_vox_mem.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                              C.POINTER(C.c_long)]
+        L.vrth_world_insert.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_float, C.c_float,
+                                        C.c_float]
+        L.vrth_world_insert_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
+                                             C.c_float]
+        L.vrth_world_remove.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.vrth_world_find.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
+        L.vrth_world_ray_cast.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                          C.POINTER(C.c_int32), C.POINTER(C.c_int)]
+        L.vrth_world_texel_count.restype = C.c_size_t
+        L.vrth_world_texel_count.argtypes = [C.c_void_p]
+        L.vrth_world_flatten.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                         C.POINTER(C.c_uint32)]
+        L.vrth_free.argtypes = [C.c_void_p]
+        L.vrth_camera_block.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_int, C.c_int,
+                                        C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                        C.POINTER(C.c_float)]
+        L.vrth_write_vox.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.vrth_encode_vox.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.vrth_make_custom_vox.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.vrth_world_fill_terrain.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.vrth_fnv1a64.restype = C.c_uint64
+        L.vrth_fnv1a64.argtypes = [C.c_void_p, C.c_size_t]
+        L.vrth_version.restype = C.c_char_p
+        _host = L
+    return _host
+
+
+def hip_lib():
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB):
+            raise VrtError(f"{HIP_LIB} is missing: the HIP extension must be built (make -C {CSRC}); "
+                           "there is no CPU fallback")
+        L = C.CDLL(HIP_LIB)
+        L.vrt_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.vrt_destroy.argtypes = [C.c_void_p]
+        L.vrt_last_error.restype = C.c_char_p
+        L.vrt_last_error.argtypes = [C.c_void_p]
+        L.vrt_default_params.argtypes = [C.POINTER(Params)]
+        L.vrt_set_params.argtypes = [C.c_void_p, C.POINTER(Params)]
+        L.vrt_upload_octree.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]
+        L.vrt_get_scene_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
+        L.vrt_set_camera.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.vrt_dispatch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.vrt_dispatch_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]
+        L.vrt_dispatch_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vrt_shard_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+        L.vrt_dispatch_timed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+        L.vrt_synchronize.argtypes = [C.c_void_p]
+        L.vrt_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.vrt_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+        L.vrt_stream.restype = C.c_void_p
+        L.vrt_stream.argtypes = [C.c_void_p]
+        L.vrt_device.argtypes = [C.c_void_p]
+        L.vrt_set_variant.argtypes = [C.c_void_p, C.c_int]
+        L.vrt_version.restype = C.c_char_p
+        L.vrt_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.vrt_debug_build_layout.restype = C.c_long
+        L.vrt_debug_build_layout.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(SceneInfo)]
+        _hip = L
+    return _hip
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class World:
+    """An octree root plus the host API calls around it (octree.hpp / voxReader.hpp)."""
+
+    def __init__(self, world_min=None, world_max=None):
+        L = host_lib()
+        mn = (C.c_int32 * 3)(*world_min) if world_min is not None else None
+        mx = (C.c_int32 * 3)(*world_max) if world_max is not None else None
+        self._h = L.vrth_world_create(mn, mx)
+        if not self._h:
+            raise VrtError("vrth_world_create failed")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            host_lib().vrth_world_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def load_vox(self, path, offset=(0, 0, 0)):
+        return bool(host_lib().vrth_world_load_vox(self._h, str(path).encode(), *offset))
+
+    def load_vox_bytes(self, data, offset=(0, 0, 0)):
+        n = C.c_long(0)
+        ok = host_lib().vrth_world_load_vox_mem(self._h, bytes(data), len(data), *offset, C.byref(n))
+        return bool(ok), n.value
+
+    def insert(self, x, y, z, rgba, refraction=3.0, illumination=0.0, k=0.0):
+        host_lib().vrth_world_insert(self._h, x, y, z, rgba, refraction, illumination, k)
+
+    def insert_many(self, xyz, rgba, refraction=3.0, illumination=0.0, k=0.0):
+        xyz = np.ascontiguousarray(xyz, np.int32).reshape(-1, 3)
+        rgba = np.ascontiguousarray(rgba, np.uint32).reshape(-1)
+        assert xyz.shape[0] == rgba.shape[0]
+        host_lib().vrth_world_insert_many(self._h, xyz.ctypes.data, rgba.ctypes.data, xyz.shape[0], refraction,
+                                          illumination, k)
+
+    def remove(self, x, y, z):
+        host_lib().vrth_world_remove(self._h, x, y, z)
+
+    def find(self, x, y, z):
+        out = (C.c_uint32 * 7)()
+        host_lib().vrth_world_find(self._h, x, y, z, out)
+        f = np.array(out[4:7], np.uint32).view(np.float32)
+        return {"coord": tuple(int(np.int32(np.uint32(v))) for v in out[0:3]), "color": int(out[3]),
+                "refraction": float(f[0]), "illumination": float(f[1]), "k": float(f[2])}
+
+    def ray_cast(self, origin, direction):
+        o = (C.c_float * 3)(*origin)
+        d = (C.c_float * 3)(*direction)
+        hit = (C.c_int32 * 3)()
+        has = C.c_int(0)
+        r = host_lib().vrth_world_ray_cast(self._h, o, d, hit, C.byref(has))
+        return (tuple(hit), bool(has.value)) if r == 1 else None
+
+    def texel_count(self):
+        return host_lib().vrth_world_texel_count(self._h)
+
+    def flatten(self):
+        """-> (uint8 ndarray with the octree_texture() bytes, tex_dim)"""
+        p = C.c_void_p()
+        n = C.c_size_t(0)
+        d = C.c_uint32(0)
+        if host_lib().vrth_world_flatten(self._h, C.byref(p), C.byref(n), C.byref(d)) != 0:
+            raise VrtError("vrth_world_flatten failed")
+        if not p.value:
+            return np.zeros(0, np.uint8), int(d.value)
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).copy()
+        host_lib().vrth_free(p)
+        return arr, int(d.value)
+
+    def fill_terrain(self, size=1024, seed=1337):
+        if host_lib().vrth_world_fill_terrain(self._h, size, seed) != 0:
+            raise VrtError("vrth_world_fill_terrain failed")
+
+
+def camera_block(pos, yaw, pitch, width, height):
+    """Camera(pos, up, yaw, pitch) -> (inv_projection[16], inv_view[16], camera_pos[4], front[3]) float32."""
+    ip, iv = np.zeros(16, np.float32), np.zeros(16, np.float32)
+    cp, fr = np.zeros(4, np.float32), np.zeros(3, np.float32)
+    p = (C.c_float * 3)(*pos)
+    if host_lib().vrth_camera_block(p, yaw, pitch, width, height, _fptr(ip), _fptr(iv), _fptr(cp), _fptr(fr)) != 0:
+        raise VrtError("vrth_camera_block failed")
+    return ip, iv, cp, fr
+
+
+def encode_vox(size, xyzi, palette=None):
+    xyzi = np.ascontiguousarray(xyzi, np.uint8).reshape(-1, 4)
+    pal = np.ascontiguousarray(palette, np.uint8).reshape(256, 4) if palette is not None else None
+    out, n = C.c_void_p(), C.c_size_t(0)
+    r = host_lib().vrth_encode_vox(size[0], size[1], size[2], xyzi.ctypes.data, xyzi.shape[0],
+                                   pal.ctypes.data if pal is not None else None, C.byref(out), C.byref(n))
+    if r != 0:
+        raise VrtError("vrth_encode_vox failed")
+    data = C.string_at(out, n.value)
+    host_lib().vrth_free(out)
+    return data
+
+
+def make_custom_vox():
+    out, n = C.c_void_p(), C.c_size_t(0)
+    if host_lib().vrth_make_custom_vox(C.byref(out), C.byref(n)) != 0:
+        raise VrtError("vrth_make_custom_vox failed")
+    data = C.string_at(out, n.value)
+    host_lib().vrth_free(out)
+    return data
+
+
+def fnv1a64(arr):
+    a = np.ascontiguousarray(arr)
+    return int(host_lib().vrth_fnv1a64(a.ctypes.data, a.nbytes))
+
+
+def build_layout(texels):
+    """Host-only: the device record array the uploader would build -> (uint32[n,2], SceneInfo)."""
+    L = hip_lib()
+    t = np.ascontiguousarray(texels, np.uint8)
+    info = SceneInfo()
+    n = L.vrt_debug_build_layout(t.ctypes.data if t.size else None, t.size, None, 0, C.byref(info))
+    if n < 0:
+        raise VrtError("malformed texel stream")
+    rec = np.zeros((n, 2), np.uint32)
+    L.vrt_debug_build_layout(t.ctypes.data if t.size else None, t.size, rec.ctypes.data, n, None)
+    return rec, info
+
+
+class Context:
+    """One GPU's dispatch context (vrt_ctx)."""
+
+    def __init__(self, device=0):
+        L = hip_lib()
+        h = C.c_void_p()
+        r = L.vrt_create(device, C.byref(h))
+        if r != 0:
+            raise VrtError(f"vrt_create({device}) failed ({r}): {L.vrt_last_error(None).decode()}")
+        self._h = h
+        self._L = L
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.vrt_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _chk(self, r):
+        if r != 0:
+            raise VrtError(f"vrt error {r}: {self._L.vrt_last_error(self._h).decode()}")
+
+    def upload_octree(self, texels, tex_dim):
+        t = np.ascontiguousarray(texels, np.uint8)
+        self._chk(self._L.vrt_upload_octree(self._h, t.ctypes.data if t.size else None, t.size, tex_dim))
+
+    def scene_info(self):
+        info = SceneInfo()
+        self._chk(self._L.vrt_get_scene_info(self._h, C.byref(info)))
+        return {k: getattr(info, k) for k, _ in SceneInfo._fields_}
+
+    def set_camera(self, inv_proj, inv_view, cam_pos):
+        ip = np.ascontiguousarray(inv_proj, np.float32)
+        iv = np.ascontiguousarray(inv_view, np.float32)
+        cp = np.ascontiguousarray(cam_pos, np.float32)
+        self._chk(self._L.vrt_set_camera(self._h, _fptr(ip), _fptr(iv), _fptr(cp)))
+
+    def default_params(self):
+        p = Params()
+        self._L.vrt_default_params(C.byref(p))
+        return p
+
+    def set_params(self, p):
+        self._chk(self._L.vrt_set_params(self._h, C.byref(p)))
+
+    def set_variant(self, v):
+        self._chk(self._L.vrt_set_variant(self._h, v))
+
+    def dispatch(self, width, height, mode=MODE_PRIMARY):
+        """Synchronous frame into host arrays -> (rgba8[H,W,4] uint8, id_dist[H,W,2] int32)."""
+        rgba = np.zeros((height, width, 4), np.uint8)
+        idd = np.zeros((height, width, 2), np.int32)
+        self._chk(self._L.vrt_dispatch(self._h, width, height, mode, rgba.ctypes.data, idd.ctypes.data))
+        return rgba, idd
+
+    def dispatch_rows(self, width, height, row_begin, row_end, mode, d_rgba, d_id, stream=None):
+        self._chk(self._L.vrt_dispatch_rows(self._h, width, height, row_begin, row_end, mode, d_rgba, d_id, stream))
+
+    def dispatch_shard(self, width, height, tile_rows, shard, n_shards, mode, d_rgba, d_id, stream=None):
+        self._chk(self._L.vrt_dispatch_shard(self._h, width, height, tile_rows, shard, n_shards, mode, d_rgba, d_id,
+                                             stream))
+
+    def dispatch_timed(self, width, height, row_begin, row_end, mode, d_rgba, d_id, iters, stream=None):
+        ms = (C.c_float * iters)()
+        self._chk(self._L.vrt_dispatch_timed(self._h, width, height, row_begin, row_end, mode, d_rgba, d_id, stream,
+                                             iters, ms))
+        return np.array(ms, np.float32)
+
+    def set_profiling(self, max_launches):
+        self._chk(self._L.vrt_set_profiling(self._h, max_launches))
+
+    def profile_read(self, cap=4096):
+        ms = (C.c_float * cap)()
+        n = self._L.vrt_profile_read(self._h, ms, cap)
+        if n < 0:
+            self._chk(n)
+        return np.array(ms[:n], np.float32)
+
+    def synchronize(self):
+        self._chk(self._L.vrt_synchronize(self._h))
+
+    @property
+    def stream(self):
+        return self._L.vrt_stream(self._h)
+
+    def debug_math(self, op, x, y):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.ascontiguousarray(y, np.float32)
+        out = np.zeros_like(x)
+        self._chk(self._L.vrt_debug_math(self._h, op, x.ctypes.data, y.ctypes.data, out.ctypes.data, x.size))
+        return out
+
+
+def shard_rows(height, tile_rows, shard, n_shards):
+    return hip_lib().vrt_shard_rows(height, tile_rows, shard, n_shards)
+
+
+def shard_row_indices(height, tile_rows, shard, n_shards):
+    """Frame rows owned by a shard under the interleaved row-tile scheme, in compact order."""
+    rows = []
+    tiles = (height + tile_rows - 1) // tile_rows
+    for t in range(shard, tiles, n_shards):
+        rows.extend(range(t * tile_rows, min(height, (t + 1) * tile_rows)))
+    return rows

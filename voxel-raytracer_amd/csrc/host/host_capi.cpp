@@ -1,0 +1,247 @@
+// host_capi.cpp -- C-ABI of include/vrt_host.h over the C++ host library.
+#include "../../../include/vrt_host.h"
+
+#include <Camera.hpp>
+#include <octree.hpp>
+#include <voxReader.hpp>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+bool vrt_load_vox_memory(const uint8_t *data, size_t len, Octree *tree, int offsetX, int offsetY, int offsetZ,
+                         long *inserted);
+
+struct vrth_world {
+    Octree *root;
+};
+
+namespace {
+inline IVector3 iv3(int x, int y, int z) {
+    IVector3 r;
+    r.x = x; r.y = y; r.z = z;
+    return r;
+}
+inline uint32_t fbits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+void put_u32(std::vector<uint8_t> &b, uint32_t v) { for (int i = 0; i < 4; ++i) b.push_back((uint8_t)(v >> (8 * i))); }
+void put_tag(std::vector<uint8_t> &b, const char *t) { b.insert(b.end(), t, t + 4); }
+
+// classic gradient noise on a 256-periodic lattice (own implementation; the
+// reference only carries a commented-out FastNoiseLite heightmap, src/main.cpp:487-503)
+struct Noise2D {
+    uint8_t perm[512];
+    explicit Noise2D(uint32_t seed) {
+        uint8_t p[256];
+        for (int i = 0; i < 256; ++i) p[i] = (uint8_t)i;
+        uint32_t s = seed * 747796405u + 2891336453u;
+        for (int i = 255; i > 0; --i) {
+            s = s * 1664525u + 1013904223u;
+            int j = (int)((s >> 8) % (uint32_t)(i + 1));
+            uint8_t t = p[i]; p[i] = p[j]; p[j] = t;
+        }
+        for (int i = 0; i < 512; ++i) perm[i] = p[i & 255];
+    }
+    static double fade(double t) { return t * t * t * (t * (t * 6.0 - 15.0) + 10.0); }
+    static double grad(int h, double x, double y) {
+        switch (h & 7) {
+            case 0: return x + y; case 1: return x - y; case 2: return -x + y; case 3: return -x - y;
+            case 4: return x; case 5: return -x; case 6: return y; default: return -y;
+        }
+    }
+    double at(double x, double y) const {
+        const int xi = (int)floor(x) & 255, yi = (int)floor(y) & 255;
+        const double xf = x - floor(x), yf = y - floor(y), u = fade(xf), v = fade(yf);
+        const int aa = perm[perm[xi] + yi], ab = perm[perm[xi] + yi + 1];
+        const int ba = perm[perm[xi + 1] + yi], bb = perm[perm[xi + 1] + yi + 1];
+        const double x1 = grad(aa, xf, yf) + u * (grad(ba, xf - 1, yf) - grad(aa, xf, yf));
+        const double x2 = grad(ab, xf, yf - 1) + u * (grad(bb, xf - 1, yf - 1) - grad(ab, xf, yf - 1));
+        return (x1 + v * (x2 - x1)) * 0.7071067811865476;  // ~[-1,1]
+    }
+};
+}  // namespace
+
+extern "C" {
+
+const char *vrth_version(void) { return "vrt-host 0.1"; }
+
+vrth_world *vrth_world_create(const int32_t *mn, const int32_t *mx) {
+    vrth_world *w = new (std::nothrow) vrth_world();
+    if (!w) return NULL;
+    const IVector3 lo = mn ? iv3(mn[0], mn[1], mn[2]) : iv3(-1023, -1023, -1023);
+    const IVector3 hi = mx ? iv3(mx[0], mx[1], mx[2]) : iv3(1024, 1024, 1024);
+    w->root = octree_create(NULL, lo, hi);
+    if (!w->root) { delete w; return NULL; }
+    return w;
+}
+
+void vrth_world_destroy(vrth_world *w) {
+    if (!w) return;
+    octree_delete(w->root);
+    delete w;
+}
+
+void *vrth_world_root(vrth_world *w) { return w ? w->root : NULL; }
+
+int vrth_world_load_vox(vrth_world *w, const char *path, int ox, int oy, int oz) {
+    if (!w) return -1;
+    return load_vox_file(path, w->root, ox, oy, oz) ? 1 : 0;
+}
+
+int vrth_world_load_vox_mem(vrth_world *w, const uint8_t *data, size_t len, int ox, int oy, int oz, long *inserted) {
+    if (!w || (!data && len)) return -1;
+    return vrt_load_vox_memory(data, len, w->root, ox, oy, oz, inserted) ? 1 : 0;
+}
+
+int vrth_world_insert(vrth_world *w, int x, int y, int z, uint32_t rgba, float refraction, float illumination, float k) {
+    if (!w) return -1;
+    Voxel m = {refraction, illumination, k};
+    octree_insert(w->root, VoxelObjCreate(m, rgba, iv3(x, y, z)));
+    return 0;
+}
+
+int vrth_world_insert_many(vrth_world *w, const int32_t *xyz, const uint32_t *rgba, size_t n, float refraction,
+                           float illumination, float k) {
+    if (!w || !xyz || !rgba) return -1;
+    Voxel m = {refraction, illumination, k};
+    for (size_t i = 0; i < n; ++i) octree_insert(w->root, VoxelObjCreate(m, rgba[i], iv3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2])));
+    return 0;
+}
+
+int vrth_world_remove(vrth_world *w, int x, int y, int z) {
+    if (!w) return -1;
+    octree_remove(w->root, iv3(x, y, z));
+    return 0;
+}
+
+int vrth_world_find(vrth_world *w, int x, int y, int z, uint32_t out7[7]) {
+    if (!w || !out7) return -1;
+    const Voxel_Object v = octree_find(w->root, iv3(x, y, z));
+    out7[0] = (uint32_t)v.coord.x; out7[1] = (uint32_t)v.coord.y; out7[2] = (uint32_t)v.coord.z;
+    out7[3] = v.color;
+    out7[4] = fbits(v.voxel.refraction); out7[5] = fbits(v.voxel.illumination); out7[6] = fbits(v.voxel.k);
+    return 0;
+}
+
+int vrth_world_ray_cast(vrth_world *w, const float origin[3], const float dir[3], int32_t hit_coord[3], int *has_voxel) {
+    if (!w || !origin || !dir) return -1;
+    Ray r;
+    r.origin.x = origin[0]; r.origin.y = origin[1]; r.origin.z = origin[2];
+    r.direction.x = dir[0]; r.direction.y = dir[1]; r.direction.z = dir[2];
+    Vector3 lo, hi;
+    lo.x = lo.y = lo.z = 0.0f;
+    hi.x = hi.y = hi.z = 1024.0f;
+    Octree *n = octree_ray_cast(w->root, r, lo, hi);
+    if (!n) return 0;
+    if (hit_coord) { hit_coord[0] = n->voxel.coord.x; hit_coord[1] = n->voxel.coord.y; hit_coord[2] = n->voxel.coord.z; }
+    if (has_voxel) *has_voxel = n->has_voxel ? 1 : 0;
+    return 1;
+}
+
+size_t vrth_world_texel_count(vrth_world *w) { return w ? _octree_texel_size(w->root) : 0; }
+
+int vrth_world_flatten(vrth_world *w, uint8_t **texels, size_t *bytes, uint32_t *tex_dim) {
+    if (!w || !texels || !bytes || !tex_dim) return -1;
+    const size_t n = _octree_texel_size(w->root);
+    size_t d = (size_t)ceil(cbrt((double)n));  // src/main.cpp:265-268
+    if (d == 0) d = 1;
+    *tex_dim = (uint32_t)d;
+    size_t used = 0;
+    *texels = octree_texture(w->root, &used, d);
+    *bytes = *texels ? used : 0;
+    return 0;
+}
+
+void vrth_free(void *p) { free(p); }
+
+int vrth_camera_block(const float pos[3], float yaw, float pitch, int width, int height, float inv_projection[16],
+                      float inv_view[16], float camera_pos[4], float *front3) {
+    if (!pos || !inv_projection || !inv_view || !camera_pos || width < 1 || height < 1) return -1;
+    Camera cam(vrtm::vec3(pos[0], pos[1], pos[2]), vrtm::vec3(0.0f, 1.0f, 0.0f), yaw, pitch);
+    cam.FillDispatchBlock(width, height, inv_projection, inv_view, camera_pos);
+    if (front3) { front3[0] = cam.Front.x; front3[1] = cam.Front.y; front3[2] = cam.Front.z; }
+    return 0;
+}
+
+int vrth_encode_vox(int sx, int sy, int sz, const uint8_t *xyzi, size_t n, const uint8_t *palette, uint8_t **out, size_t *out_len) {
+    if (!out || !out_len || (!xyzi && n) || sx < 1 || sy < 1 || sz < 1) return -1;
+    std::vector<uint8_t> body;
+    put_tag(body, "SIZE"); put_u32(body, 12); put_u32(body, 0);
+    put_u32(body, (uint32_t)sx); put_u32(body, (uint32_t)sy); put_u32(body, (uint32_t)sz);
+    put_tag(body, "XYZI"); put_u32(body, (uint32_t)(4 + 4 * n)); put_u32(body, 0);
+    put_u32(body, (uint32_t)n);
+    body.insert(body.end(), xyzi, xyzi + 4 * n);
+    if (palette) {
+        put_tag(body, "RGBA"); put_u32(body, 1024); put_u32(body, 0);
+        body.insert(body.end(), palette, palette + 1024);
+    }
+    std::vector<uint8_t> file;
+    put_tag(file, "VOX "); put_u32(file, 150);
+    put_tag(file, "MAIN"); put_u32(file, 0); put_u32(file, (uint32_t)body.size());
+    file.insert(file.end(), body.begin(), body.end());
+    // the reference's chunk loop stops 12 bytes before the end of the file (src/voxReader.cpp:256),
+    // so a chunk header must never be the last thing it needs; pad like exporters' trailing chunks do
+    *out = (uint8_t *)malloc(file.size());
+    if (!*out) return -1;
+    memcpy(*out, file.data(), file.size());
+    *out_len = file.size();
+    return 0;
+}
+
+int vrth_write_vox(const char *path, int sx, int sy, int sz, const uint8_t *xyzi, size_t n, const uint8_t *palette) {
+    uint8_t *buf = NULL;
+    size_t len = 0;
+    if (!path || vrth_encode_vox(sx, sy, sz, xyzi, n, palette, &buf, &len) != 0) return -1;
+    FILE *fp = fopen(path, "wb");
+    if (!fp) { free(buf); return -1; }
+    const size_t w = fwrite(buf, 1, len, fp);
+    fclose(fp);
+    free(buf);
+    return w == len ? 0 : -1;
+}
+
+// 64^3 model, floor slab z<4, solid sphere r=24 at (32,32,36);
+// colorIndex = 1 + ((x*7 + y*13 + z*29) % 255); palette[i] = (i, 255-i, (i*37)&255, 255)
+int vrth_make_custom_vox(uint8_t **out, size_t *out_len) {
+    std::vector<uint8_t> xyzi;
+    for (int z = 0; z < 64; ++z)
+        for (int y = 0; y < 64; ++y)
+            for (int x = 0; x < 64; ++x) {
+                const int dx = x - 32, dy = y - 32, dz = z - 36;
+                if (z < 4 || dx * dx + dy * dy + dz * dz <= 24 * 24) {
+                    xyzi.push_back((uint8_t)x); xyzi.push_back((uint8_t)y); xyzi.push_back((uint8_t)z);
+                    xyzi.push_back((uint8_t)(1 + ((x * 7 + y * 13 + z * 29) % 255)));
+                }
+            }
+    uint8_t pal[1024];
+    for (int i = 0; i < 256; ++i) { pal[4 * i] = (uint8_t)i; pal[4 * i + 1] = (uint8_t)(255 - i); pal[4 * i + 2] = (uint8_t)((i * 37) & 255); pal[4 * i + 3] = 255; }
+    return vrth_encode_vox(64, 64, 64, xyzi.data(), xyzi.size() / 4, pal, out, out_len);
+}
+
+// Config 4 stand-in: size x size heightfield, surface band 8 voxels thick:
+// top layer dirt, bottom two stone, grass between (colours/materials of src/main.cpp:220-259).
+int vrth_world_fill_terrain(vrth_world *w, int size, int seed) {
+    if (!w || size < 1 || size > 1024) return -1;
+    const Noise2D noise((uint32_t)seed);
+    for (int z = 0; z < size; ++z)
+        for (int x = 0; x < size; ++x) {
+            double n = 0.6 * noise.at(x * 0.01, z * 0.01) + 0.3 * noise.at(x * 0.031, z * 0.031) + 0.1 * noise.at(x * 0.09, z * 0.09);
+            int h = (int)((n + 1.0) * 33.0 * 4.0) + 120;
+            if (h > 1000) h = 1000;
+            int lo = h - 8 < 20 ? 20 : h - 8;
+            for (int y = lo; y < h; ++y) {
+                int kind = (y == h - 1) ? 1 : (y < lo + 2 ? 5 : 0);
+                octree_insert(w->root, VoxelObjCreate(voxels[kind], voxelColors[kind], iv3(x, y, z)));
+            }
+        }
+    return 0;
+}
+
+uint64_t vrth_fnv1a64(const uint8_t *p, size_t n) {
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+}  // extern "C"

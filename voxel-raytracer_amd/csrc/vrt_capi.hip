@@ -1,0 +1,475 @@
+// vrt_capi.hip -- the C-ABI of include/vrt.h over the gfx950 kernels.
+// Built by hipcc --offload-arch=gfx950 into libvrt_hip.so. No CPU fallback.
+#include "../../include/vrt.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "vrt_kernels.hip.h"
+#include "vrt_layout.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Variant {
+    bool use_lds;
+    int tw;           // tile width in pixels (tile = tw x 64/tw)
+    int block;        // threads per workgroup
+    uint32_t lds_cap; // max records staged in LDS
+    int blocks_per_cu; // > 0: persistent grid of CUs*blocks_per_cu workgroups; 0: one pass over all tiles
+};
+
+// variant 0 is the default the library ships with; the others exist for A/B measurement
+const Variant kVariants[] = {
+    /*0*/ {true, 8, 256, 2048, 8},
+    /*1*/ {false, 8, 256, 0, 0},
+    /*2*/ {false, 16, 256, 0, 0},
+    /*3*/ {false, 64, 256, 0, 0},
+    /*4*/ {true, 8, 256, 2048, 0},
+    /*5*/ {true, 8, 1024, 8192, 2},
+    /*6*/ {true, 8, 1024, 16384, 1},
+    /*7*/ {true, 16, 256, 2048, 8},
+    /*8*/ {false, 8, 256, 0, 8},
+    /*9*/ {true, 8, 512, 4096, 4},
+};
+constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
+
+}  // namespace
+
+struct vrt_ctx {
+    int device = 0;
+    int n_cus = 256;
+    hipStream_t stream = nullptr;
+    uint2 *d_nodes = nullptr;
+    size_t nodes_capacity = 0;
+    bool have_scene = false;
+    bool have_camera = false;
+    vrt_scene_info info{};
+    vrt_params params{};
+    float inv_proj[16]{}, inv_view[16]{}, cam_pos[4]{};
+    int variant = 0;
+    // scratch outputs for the host-buffer dispatch
+    void *d_rgba = nullptr;
+    void *d_id = nullptr;
+    size_t scratch_pixels = 0;
+    // optional per-launch hipEvent pairs (vrt_set_profiling)
+    bool profiling = false;
+    std::vector<hipEvent_t> prof_events;  // 2 per slot
+    size_t prof_count = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(vrt_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define VRT_HIP(c, call)                                                                   \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail((c), VRT_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <int MODE, bool USE_LDS, int TW, int BLOCK>
+hipError_t launch_one(const vrt::KArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
+    if (lds_bytes > 64 * 1024) {  // above the default dynamic-LDS ceiling: opt in (CDNA4 has 160 KiB per CU)
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&vrt::trace_kernel<MODE, USE_LDS, TW, BLOCK>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL((vrt::trace_kernel<MODE, USE_LDS, TW, BLOCK>), dim3(grid), dim3(BLOCK), lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+template <int MODE, bool USE_LDS, int TW>
+hipError_t launch_block(int block, const vrt::KArgs &a, int grid, size_t lds, hipStream_t s) {
+    switch (block) {
+        case 256: return launch_one<MODE, USE_LDS, TW, 256>(a, grid, lds, s);
+        case 512: return launch_one<MODE, USE_LDS, TW, 512>(a, grid, lds, s);
+        case 1024: return launch_one<MODE, USE_LDS, TW, 1024>(a, grid, lds, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int MODE, bool USE_LDS>
+hipError_t launch_tw(int tw, int block, const vrt::KArgs &a, int grid, size_t lds, hipStream_t s) {
+    switch (tw) {
+        case 8: return launch_block<MODE, USE_LDS, 8>(block, a, grid, lds, s);
+        case 16: return launch_block<MODE, USE_LDS, 16>(block, a, grid, lds, s);
+        case 64: return launch_block<MODE, USE_LDS, 64>(block, a, grid, lds, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int MODE>
+hipError_t launch_mode(const Variant &v, const vrt::KArgs &a, int grid, size_t lds, hipStream_t s) {
+    return v.use_lds ? launch_tw<MODE, true>(v.tw, v.block, a, grid, lds, s)
+                     : launch_tw<MODE, false>(v.tw, v.block, a, grid, lds, s);
+}
+
+// Builds the kernel arguments for local rows [0, n_rows) and enqueues one launch.
+int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_rows, int row_stride, int compact,
+            int mode, void *d_rgba, void *d_id, hipStream_t s) {
+    if (!c->have_scene) return fail(c, VRT_E_STATE, "vrt_dispatch: no octree uploaded (call vrt_upload_octree first)");
+    if (!c->have_camera) return fail(c, VRT_E_STATE, "vrt_dispatch: no camera set (call vrt_set_camera first)");
+    if (mode != VRT_MODE_PRIMARY && mode != VRT_MODE_PRIMARY_SHADOW)
+        return fail(c, VRT_E_INVALID, mode == VRT_MODE_FULL ? "VRT_MODE_FULL is not implemented by this build"
+                                                             : "unknown mode");
+    if (n_rows <= 0) return VRT_OK;
+    const Variant &v = kVariants[c->variant];
+    vrt::KArgs a;
+    std::memcpy(a.inv_proj, c->inv_proj, sizeof a.inv_proj);
+    std::memcpy(a.inv_view, c->inv_view, sizeof a.inv_view);
+    std::memcpy(a.cam_pos, c->cam_pos, sizeof a.cam_pos);
+    a.voxel_scale = c->params.voxel_scale;
+    for (int i = 0; i < 3; ++i) {
+        a.wmin[i] = c->params.world_min[i];
+        a.wmax[i] = c->params.world_max[i];
+        a.light_dir[i] = c->params.light_dir[i];
+        a.highlighted[i] = c->params.highlighted[i];
+    }
+    for (int i = 0; i < 4; ++i) a.global_light[i] = c->params.global_light[i];
+    a.tex_dim = (int)c->info.tex_dim;
+    a.width = width;
+    a.height = height;
+    a.row0 = row0;
+    a.n_rows = n_rows;
+    a.tile_rows = tile_rows;
+    a.row_stride = row_stride;
+    a.compact = compact;
+    a.nodes = c->d_nodes;
+    a.n_records = c->info.n_records;
+    a.lds_records = v.use_lds ? (c->info.n_records < v.lds_cap ? c->info.n_records : v.lds_cap) : 0u;
+    a.out_rgba = (uint32_t *)d_rgba;
+    a.out_id = (int2 *)d_id;
+
+    const int th = 64 / v.tw;
+    const long tiles = (long)((width + v.tw - 1) / v.tw) * (long)((n_rows + th - 1) / th);
+    const int waves = v.block / 64;
+    long grid = (tiles + waves - 1) / waves;
+    if (v.blocks_per_cu > 0) {
+        long cap = (long)c->n_cus * v.blocks_per_cu;
+        if (grid > cap) grid = cap;
+    }
+    if (grid < 1) grid = 1;
+    const size_t lds_bytes = (size_t)a.lds_records * sizeof(uint2);
+    const bool prof = c->profiling && (c->prof_count + 1) * 2 <= c->prof_events.size();
+    if (prof) VRT_HIP(c, hipEventRecord(c->prof_events[2 * c->prof_count], s));
+    hipError_t e = (mode == VRT_MODE_PRIMARY) ? launch_mode<0>(v, a, (int)grid, lds_bytes, s)
+                                              : launch_mode<1>(v, a, (int)grid, lds_bytes, s);
+    if (e != hipSuccess) return fail(c, VRT_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    if (prof) {
+        VRT_HIP(c, hipEventRecord(c->prof_events[2 * c->prof_count + 1], s));
+        ++c->prof_count;
+    }
+    c->info.lds_records = a.lds_records;
+    return VRT_OK;
+}
+
+int check_frame(vrt_ctx *c, int width, int height) {
+    if (!c) return VRT_E_INVALID;
+    if (width < 1 || height < 1 || (long)width * (long)height > (1L << 30))
+        return fail(c, VRT_E_INVALID, "width/height out of range");
+    return VRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *vrt_version(void) { return "vrt-hip 0.1 (gfx950)"; }
+
+void vrt_default_params(vrt_params *p) {
+    if (!p) return;
+    p->voxel_scale = 1.0f;  // src/main.cpp:638
+    for (int i = 0; i < 3; ++i) {
+        p->world_min[i] = -1023;  // src/main.cpp:478-480
+        p->world_max[i] = 1024;
+        p->highlighted[i] = -1;   // src/main.cpp:816
+    }
+    for (int i = 0; i < 4; ++i) p->global_light[i] = 1.0f;  // src/main.cpp:482
+    // glm::normalize(vec3(0.3481553, 0.870388, 0.3481553)), src/main.cpp:483
+    const float l[3] = {0.3481553f, 0.870388f, 0.3481553f};
+    const float t0 = l[0] * l[0], t1 = l[1] * l[1], t2 = l[2] * l[2];
+    const float inv = 1.0f / sqrtf(t0 + t1 + t2);
+    for (int i = 0; i < 3; ++i) p->light_dir[i] = l[i] * inv;
+}
+
+int vrt_create(int device_id, vrt_ctx **out) {
+    if (!out) return VRT_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_error = std::string("vrt_create: no HIP device (") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0") +
+                         "); this library has no CPU path";
+        return VRT_E_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n) {
+        g_create_error = "vrt_create: device_id out of range";
+        return VRT_E_INVALID;
+    }
+    vrt_ctx *c = new (std::nothrow) vrt_ctx();
+    if (!c) return VRT_E_INVALID;
+    c->device = device_id;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_create_error = std::string("vrt_create: ") + hipGetErrorString(e);
+        delete c;
+        return VRT_E_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
+    vrt_default_params(&c->params);
+    *out = c;
+    return VRT_OK;
+}
+
+void vrt_destroy(vrt_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_nodes) (void)hipFree(c->d_nodes);
+    if (c->d_rgba) (void)hipFree(c->d_rgba);
+    if (c->d_id) (void)hipFree(c->d_id);
+    for (auto &e : c->prof_events) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *vrt_last_error(const vrt_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int vrt_set_params(vrt_ctx *c, const vrt_params *p) {
+    if (!c || !p) return c ? fail(c, VRT_E_INVALID, "vrt_set_params: null params") : VRT_E_INVALID;
+    for (int i = 0; i < 3; ++i)
+        if (p->world_max[i] < p->world_min[i]) return fail(c, VRT_E_INVALID, "vrt_set_params: world_max < world_min");
+    c->params = *p;
+    return VRT_OK;
+}
+
+int vrt_upload_octree(vrt_ctx *c, const uint8_t *texels, size_t used_bytes, uint32_t tex_dim) {
+    if (!c) return VRT_E_INVALID;
+    if (used_bytes % 4 != 0) return fail(c, VRT_E_INVALID, "vrt_upload_octree: used_bytes must be a multiple of 4");
+    if (used_bytes / 4 > (1u << 23)) return fail(c, VRT_E_MALFORMED, "vrt_upload_octree: more than 2^23 texels cannot be addressed by 23-bit node pointers");
+    if (tex_dim == 0) tex_dim = 1;
+    vrt::Layout lay;
+    std::string err;
+    if (!vrt::build_layout(texels, used_bytes, lay, err)) return fail(c, VRT_E_MALFORMED, "vrt_upload_octree: " + err);
+    VRT_HIP(c, hipSetDevice(c->device));
+    const size_t bytes = lay.records.size() * sizeof(vrt::Record);
+    if (bytes > c->nodes_capacity) {
+        VRT_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->d_nodes) VRT_HIP(c, hipFree(c->d_nodes));
+        c->d_nodes = nullptr;
+        c->nodes_capacity = 0;
+        VRT_HIP(c, hipMalloc((void **)&c->d_nodes, bytes));
+        c->nodes_capacity = bytes;
+    }
+    // stream-ordered after any dispatch still reading the old tree; synchronous so `lay` may die
+    VRT_HIP(c, hipMemcpyAsync(c->d_nodes, lay.records.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    VRT_HIP(c, hipStreamSynchronize(c->stream));
+    c->info.tex_dim = tex_dim;
+    c->info.n_texels = (uint32_t)(used_bytes / 4);
+    c->info.n_records = (uint32_t)lay.records.size();
+    c->info.n_internal = lay.n_internal;
+    c->info.n_leaves = lay.n_leaves;
+    c->info.max_depth = lay.max_depth;
+    c->info.lds_records = 0;
+    c->have_scene = true;
+    return VRT_OK;
+}
+
+int vrt_get_scene_info(const vrt_ctx *c, vrt_scene_info *info) {
+    if (!c || !info) return VRT_E_INVALID;
+    *info = c->info;
+    return VRT_OK;
+}
+
+int vrt_set_camera(vrt_ctx *c, const float inv_projection[16], const float inv_view[16], const float camera_pos[4]) {
+    if (!c) return VRT_E_INVALID;
+    if (!inv_projection || !inv_view || !camera_pos) return fail(c, VRT_E_INVALID, "vrt_set_camera: null pointer");
+    std::memcpy(c->inv_proj, inv_projection, sizeof c->inv_proj);
+    std::memcpy(c->inv_view, inv_view, sizeof c->inv_view);
+    std::memcpy(c->cam_pos, camera_pos, sizeof c->cam_pos);
+    c->have_camera = true;
+    return VRT_OK;
+}
+
+int vrt_set_variant(vrt_ctx *c, int variant) {
+    if (!c) return VRT_E_INVALID;
+    if (variant < 0 || variant >= kNumVariants) return fail(c, VRT_E_INVALID, "vrt_set_variant: unknown variant");
+    c->variant = variant;
+    return VRT_OK;
+}
+
+int vrt_dispatch_rows(vrt_ctx *c, int width, int height, int row_begin, int row_end, int mode, void *d_rgba8,
+                      void *d_id_dist, void *stream) {
+    int r = check_frame(c, width, height);
+    if (r) return r;
+    if (row_begin < 0 || row_end > height || row_begin > row_end) return fail(c, VRT_E_INVALID, "vrt_dispatch_rows: bad row range");
+    VRT_HIP(c, hipSetDevice(c->device));
+    const int n = row_end - row_begin;
+    return enqueue(c, width, height, row_begin, n, n > 0 ? n : 1, 0, 0, mode, d_rgba8, d_id_dist,
+                   stream ? (hipStream_t)stream : c->stream);
+}
+
+int vrt_shard_rows(int height, int tile_rows, int shard, int n_shards) {
+    if (height < 1 || tile_rows < 1 || n_shards < 1 || shard < 0 || shard >= n_shards) return VRT_E_INVALID;
+    const int tiles = (height + tile_rows - 1) / tile_rows;
+    int rows = 0;
+    for (int t = shard; t < tiles; t += n_shards) {
+        const int r0 = t * tile_rows;
+        rows += (r0 + tile_rows <= height) ? tile_rows : height - r0;
+    }
+    return rows;
+}
+
+int vrt_dispatch_shard(vrt_ctx *c, int width, int height, int tile_rows, int shard, int n_shards, int mode,
+                       void *d_rgba8, void *d_id_dist, void *stream) {
+    int r = check_frame(c, width, height);
+    if (r) return r;
+    const int rows = vrt_shard_rows(height, tile_rows, shard, n_shards);
+    if (rows < 0) return fail(c, VRT_E_INVALID, "vrt_dispatch_shard: bad tile_rows/shard/n_shards");
+    VRT_HIP(c, hipSetDevice(c->device));
+    return enqueue(c, width, height, shard * tile_rows, rows, tile_rows, tile_rows * n_shards, 1, mode, d_rgba8,
+                   d_id_dist, stream ? (hipStream_t)stream : c->stream);
+}
+
+int vrt_dispatch(vrt_ctx *c, int width, int height, int mode, uint8_t *out_rgba8, int32_t *out_id_dist) {
+    int r = check_frame(c, width, height);
+    if (r) return r;
+    VRT_HIP(c, hipSetDevice(c->device));
+    const size_t px = (size_t)width * (size_t)height;
+    if (px > c->scratch_pixels) {
+        VRT_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->d_rgba) VRT_HIP(c, hipFree(c->d_rgba));
+        if (c->d_id) VRT_HIP(c, hipFree(c->d_id));
+        c->d_rgba = c->d_id = nullptr;
+        c->scratch_pixels = 0;
+        VRT_HIP(c, hipMalloc(&c->d_rgba, px * 4));
+        VRT_HIP(c, hipMalloc(&c->d_id, px * 8));
+        c->scratch_pixels = px;
+    }
+    r = enqueue(c, width, height, 0, height, height, 0, 0, mode, out_rgba8 ? c->d_rgba : nullptr,
+                out_id_dist ? c->d_id : nullptr, c->stream);
+    if (r) return r;
+    if (out_rgba8) VRT_HIP(c, hipMemcpyAsync(out_rgba8, c->d_rgba, px * 4, hipMemcpyDeviceToHost, c->stream));
+    if (out_id_dist) VRT_HIP(c, hipMemcpyAsync(out_id_dist, c->d_id, px * 8, hipMemcpyDeviceToHost, c->stream));
+    VRT_HIP(c, hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+
+int vrt_dispatch_timed(vrt_ctx *c, int width, int height, int row_begin, int row_end, int mode, void *d_rgba8,
+                       void *d_id_dist, void *stream, int iters, float *ms_out) {
+    int r = check_frame(c, width, height);
+    if (r) return r;
+    if (iters < 1 || !ms_out) return fail(c, VRT_E_INVALID, "vrt_dispatch_timed: iters/ms_out");
+    if (row_begin < 0 || row_end > height || row_begin >= row_end) return fail(c, VRT_E_INVALID, "vrt_dispatch_timed: bad row range");
+    VRT_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    std::vector<hipEvent_t> ev((size_t)iters * 2);
+    for (auto &e : ev) VRT_HIP(c, hipEventCreate(&e));
+    int rc = VRT_OK;
+    const int n = row_end - row_begin;
+    for (int i = 0; i < iters && rc == VRT_OK; ++i) {
+        VRT_HIP(c, hipEventRecord(ev[2 * i], s));
+        rc = enqueue(c, width, height, row_begin, n, n, 0, 0, mode, d_rgba8, d_id_dist, s);
+        VRT_HIP(c, hipEventRecord(ev[2 * i + 1], s));
+    }
+    VRT_HIP(c, hipStreamSynchronize(s));
+    if (rc == VRT_OK)
+        for (int i = 0; i < iters; ++i) VRT_HIP(c, hipEventElapsedTime(&ms_out[i], ev[2 * i], ev[2 * i + 1]));
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+int vrt_synchronize(vrt_ctx *c) {
+    if (!c) return VRT_E_INVALID;
+    VRT_HIP(c, hipSetDevice(c->device));
+    VRT_HIP(c, hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+
+int vrt_set_profiling(vrt_ctx *c, int max_launches) {
+    if (!c) return VRT_E_INVALID;
+    VRT_HIP(c, hipSetDevice(c->device));
+    c->prof_count = 0;
+    c->profiling = max_launches > 0;
+    while (c->profiling && c->prof_events.size() < (size_t)max_launches * 2) {
+        hipEvent_t e;
+        VRT_HIP(c, hipEventCreate(&e));
+        c->prof_events.push_back(e);
+    }
+    return VRT_OK;
+}
+
+int vrt_profile_read(vrt_ctx *c, float *ms_out, int cap) {
+    if (!c || !ms_out || cap < 0) return VRT_E_INVALID;
+    VRT_HIP(c, hipSetDevice(c->device));
+    int n = 0;
+    for (size_t i = 0; i < c->prof_count && n < cap; ++i, ++n) {
+        VRT_HIP(c, hipEventSynchronize(c->prof_events[2 * i + 1]));
+        VRT_HIP(c, hipEventElapsedTime(&ms_out[n], c->prof_events[2 * i], c->prof_events[2 * i + 1]));
+    }
+    c->prof_count = 0;
+    return n;
+}
+
+void *vrt_stream(vrt_ctx *c) { return c ? (void *)c->stream : nullptr; }
+int vrt_device(const vrt_ctx *c) { return c ? c->device : VRT_E_INVALID; }
+
+// Arithmetic-contract probe (see math_probe_kernel): host arrays in/out, synchronous.
+int vrt_debug_math(vrt_ctx *c, int op, const float *x, const float *y, float *out, int n) {
+    if (!c || !x || !y || !out || n < 1) return VRT_E_INVALID;
+    VRT_HIP(c, hipSetDevice(c->device));
+    float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    const size_t bytes = (size_t)n * sizeof(float);
+    VRT_HIP(c, hipMalloc((void **)&dx, bytes));
+    VRT_HIP(c, hipMalloc((void **)&dy, bytes));
+    VRT_HIP(c, hipMalloc((void **)&dout, bytes));
+    VRT_HIP(c, hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, c->stream));
+    VRT_HIP(c, hipMemcpyAsync(dy, y, bytes, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(vrt::math_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, op, dx, dy, dout, n);
+    VRT_HIP(c, hipGetLastError());
+    VRT_HIP(c, hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, c->stream));
+    VRT_HIP(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
+    return VRT_OK;
+}
+
+// Host-only view of the device layout for tests that run without a GPU:
+// writes up to cap records (8 bytes each) and returns the record count, or <0.
+long vrt_debug_build_layout(const uint8_t *texels, size_t used_bytes, uint32_t *records_out, size_t cap_records,
+                            vrt_scene_info *info) {
+    vrt::Layout lay;
+    std::string err;
+    if (!vrt::build_layout(texels, used_bytes, lay, err)) return VRT_E_MALFORMED;
+    if (records_out)
+        for (size_t i = 0; i < lay.records.size() && i < cap_records; ++i) {
+            records_out[2 * i] = lay.records[i].w0;
+            records_out[2 * i + 1] = lay.records[i].w1;
+        }
+    if (info) {
+        std::memset(info, 0, sizeof *info);
+        info->n_texels = (uint32_t)(used_bytes / 4);
+        info->n_records = (uint32_t)lay.records.size();
+        info->n_internal = lay.n_internal;
+        info->n_leaves = lay.n_leaves;
+        info->max_depth = lay.max_depth;
+    }
+    return (long)lay.records.size();
+}
+
+}  // extern "C"
