@@ -94,6 +94,13 @@ def hip_lib():
         if not os.path.exists(HIP_LIB):
             raise VrtError(f"{HIP_LIB} is missing: the HIP extension must be built (make -C {CSRC}); "
                            "there is no CPU fallback")
+        # One HIP runtime per process: torch bundles its own libamdhip64 (SONAME libamdhip64.so.7). Loading it
+        # first lets libvrt_hip.so bind to that copy; the other order ends with two HIP/HSA runtimes and
+        # torch reporting "No HIP GPUs are available".
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(HIP_LIB)
         L.vrt_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.vrt_destroy.argtypes = [C.c_void_p]
