@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "vrt_kernels.hip.h"
+#include "vrt_kernels_v1.hip.h"
 #include "vrt_layout.h"
 
 namespace {
@@ -18,25 +19,26 @@ namespace {
 thread_local std::string g_create_error;
 
 struct Variant {
-    bool use_lds;
-    int tw;           // tile width in pixels (tile = tw x 64/tw)
-    int block;        // threads per workgroup
-    uint32_t lds_cap; // max records staged in LDS
+    int trav;          // 2: bit-indexed descent with restart anchors (vrt_kernels.hip.h); 1: baseline (vrt_kernels_v1.hip.h)
+    bool use_lds;      // stage the level-order record prefix in LDS
+    int tw;            // tile width in pixels (tile = tw x 64/tw)
+    int block;         // threads per workgroup
+    uint32_t lds_cap;  // max records staged in LDS
     int blocks_per_cu; // > 0: persistent grid of CUs*blocks_per_cu workgroups; 0: one pass over all tiles
 };
 
 // variant 0 is the default the library ships with; the others exist for A/B measurement
 const Variant kVariants[] = {
-    /*0*/ {true, 8, 256, 2048, 8},
-    /*1*/ {false, 8, 256, 0, 0},
-    /*2*/ {false, 16, 256, 0, 0},
-    /*3*/ {false, 64, 256, 0, 0},
-    /*4*/ {true, 8, 256, 2048, 0},
-    /*5*/ {true, 8, 1024, 8192, 2},
-    /*6*/ {true, 8, 1024, 16384, 1},
-    /*7*/ {true, 16, 256, 2048, 8},
-    /*8*/ {false, 8, 256, 0, 8},
-    /*9*/ {true, 8, 512, 4096, 4},
+    /*0*/ {2, false, 8, 256, 0, 0},
+    /*1*/ {1, false, 8, 256, 0, 0},
+    /*2*/ {2, true, 8, 256, 2048, 0},
+    /*3*/ {2, false, 16, 256, 0, 0},
+    /*4*/ {2, false, 8, 512, 0, 0},
+    /*5*/ {2, true, 8, 1024, 8192, 0},
+    /*6*/ {2, false, 8, 256, 0, 8},
+    /*7*/ {1, true, 8, 256, 2048, 0},
+    /*8*/ {2, false, 64, 256, 0, 0},
+    /*9*/ {2, false, 8, 1024, 0, 0},
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -79,45 +81,43 @@ int fail(vrt_ctx *c, int code, const std::string &msg) {
             return fail((c), VRT_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-template <int MODE, bool USE_LDS, int TW, int BLOCK>
+template <int MODE, class TRAV, int TW, int BLOCK>
 hipError_t launch_one(const vrt::KArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
-    if (lds_bytes > 64 * 1024) {  // above the default dynamic-LDS ceiling: opt in (CDNA4 has 160 KiB per CU)
+    if (lds_bytes > 48 * 1024) {  // above the default dynamic-LDS ceiling: opt in (CDNA4 has 160 KiB per CU)
         static bool raised = false;
         if (!raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&vrt::trace_kernel<MODE, USE_LDS, TW, BLOCK>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&vrt::trace_kernel<MODE, TRAV, TW, BLOCK>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             if (e != hipSuccess) return e;
             raised = true;
         }
     }
-    hipLaunchKernelGGL((vrt::trace_kernel<MODE, USE_LDS, TW, BLOCK>), dim3(grid), dim3(BLOCK), lds_bytes, s, a);
+    hipLaunchKernelGGL((vrt::trace_kernel<MODE, TRAV, TW, BLOCK>), dim3(grid), dim3(BLOCK), lds_bytes, s, a);
     return hipGetLastError();
 }
 
-template <int MODE, bool USE_LDS, int TW>
-hipError_t launch_block(int block, const vrt::KArgs &a, int grid, size_t lds, hipStream_t s) {
-    switch (block) {
-        case 256: return launch_one<MODE, USE_LDS, TW, 256>(a, grid, lds, s);
-        case 512: return launch_one<MODE, USE_LDS, TW, 512>(a, grid, lds, s);
-        case 1024: return launch_one<MODE, USE_LDS, TW, 1024>(a, grid, lds, s);
-        default: return hipErrorInvalidValue;
-    }
-}
-
-template <int MODE, bool USE_LDS>
-hipError_t launch_tw(int tw, int block, const vrt::KArgs &a, int grid, size_t lds, hipStream_t s) {
-    switch (tw) {
-        case 8: return launch_block<MODE, USE_LDS, 8>(block, a, grid, lds, s);
-        case 16: return launch_block<MODE, USE_LDS, 16>(block, a, grid, lds, s);
-        case 64: return launch_block<MODE, USE_LDS, 64>(block, a, grid, lds, s);
+template <int MODE, class TRAV>
+hipError_t launch_shape(int tw, int block, const vrt::KArgs &a, int grid, size_t lds, hipStream_t s) {
+    const int key = tw * 10000 + block;
+    switch (key) {
+        case 8 * 10000 + 256: return launch_one<MODE, TRAV, 8, 256>(a, grid, lds, s);
+        case 8 * 10000 + 512: return launch_one<MODE, TRAV, 8, 512>(a, grid, lds, s);
+        case 8 * 10000 + 1024: return launch_one<MODE, TRAV, 8, 1024>(a, grid, lds, s);
+        case 16 * 10000 + 256: return launch_one<MODE, TRAV, 16, 256>(a, grid, lds, s);
+        case 64 * 10000 + 256: return launch_one<MODE, TRAV, 64, 256>(a, grid, lds, s);
         default: return hipErrorInvalidValue;
     }
 }
 
 template <int MODE>
 hipError_t launch_mode(const Variant &v, const vrt::KArgs &a, int grid, size_t lds, hipStream_t s) {
-    return v.use_lds ? launch_tw<MODE, true>(v.tw, v.block, a, grid, lds, s)
-                     : launch_tw<MODE, false>(v.tw, v.block, a, grid, lds, s);
+    if (v.trav == 1) {  // baseline traversal: one shape only
+        if (v.tw != 8 || v.block != 256) return hipErrorInvalidValue;
+        return v.use_lds ? launch_one<MODE, vrt::v1::Trav<true>, 8, 256>(a, grid, lds, s)
+                         : launch_one<MODE, vrt::v1::Trav<false>, 8, 256>(a, grid, lds, s);
+    }
+    return v.use_lds ? launch_shape<MODE, vrt::v2::Trav<true>>(v.tw, v.block, a, grid, lds, s)
+                     : launch_shape<MODE, vrt::v2::Trav<false>>(v.tw, v.block, a, grid, lds, s);
 }
 
 // Builds the kernel arguments for local rows [0, n_rows) and enqueues one launch.

@@ -1,0 +1,279 @@
+// vrt_common.hip.h -- device-side pieces shared by every traversal variant:
+// kernel arguments, the fp32 arithmetic conventions, ray generation and shading
+// of shaders/raytracing.comp (main :624-645, the primary-ray subset of pathTrace
+// :435-497, 522-544, 573-589, 619-621), and the pixel-tile kernel skeleton.
+//
+// Arithmetic contract (must hold bit-for-bit against the CPU oracle):
+//   * IEEE binary32, round-to-nearest-even, NO contraction (-ffp-contract=off),
+//     correctly rounded '/' and sqrtf (hipcc default), denormals kept.
+//   * mat4*vec4 = (m0*x + m1*y) + (m2*z + m3*w); dot3 = (x*x' + y*y') + z*z';
+//     normalize(v) = v * (1/sqrt(dot(v,v))); min(a,b) = b<a?b:a; max(a,b) = a<b?b:a.
+//   * The DDA advances one octree NODE per step exactly as hitMarching does; the
+//     node lookup may use any structure because octreeFind's result is a pure
+//     function of the query point (the deepest node containing it).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vrt {
+
+struct F3 { float x, y, z; };
+struct I3 { int x, y, z; };
+
+// Kernel arguments: passed by value (kernarg segment -> scalar loads, wave-uniform).
+struct KArgs {
+    float inv_proj[16];
+    float inv_view[16];
+    float cam_pos[4];
+    float voxel_scale;
+    int wmin[3];
+    int wmax[3];
+    float global_light[4];
+    float light_dir[3];
+    int highlighted[3];
+    int tex_dim;
+    int width, height;
+    // rows traced by this launch: local row j in [0, n_rows) maps to frame row
+    //   y = row0 + (j / tile_rows) * row_stride + (j % tile_rows)
+    int row0, n_rows, tile_rows, row_stride;
+    int compact;              // 1: outputs indexed by local row j, 0: by frame row y
+    const uint2 *nodes;       // level-ordered records (vrt_layout.h), root = record 0
+    uint32_t n_records;
+    uint32_t lds_records;     // prefix of `nodes` staged in LDS by each workgroup
+    uint32_t *out_rgba;       // packed R | G<<8 | B<<16 | A<<24
+    int2 *out_id;             // (voxelID, dist)
+};
+
+#define VRT_DEV __device__ __forceinline__
+
+VRT_DEV float fmin_c(float a, float b) { return b < a ? b : a; }
+VRT_DEV float fmax_c(float a, float b) { return a < b ? b : a; }
+VRT_DEV float dot3(F3 a, F3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+VRT_DEV float len3(F3 a) { return __builtin_sqrtf(dot3(a, a)); }
+VRT_DEV F3 scale3(F3 a, float s) { return F3{a.x * s, a.y * s, a.z * s}; }
+VRT_DEV F3 add3(F3 a, F3 b) { return F3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+VRT_DEV F3 sub3(F3 a, F3 b) { return F3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+VRT_DEV F3 normalize3(F3 a) { return scale3(a, 1.0f / __builtin_sqrtf(dot3(a, a))); }
+VRT_DEV float sign_c(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+VRT_DEV float comp(F3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+VRT_DEV I3 floor_i3(F3 p) { return I3{(int)__builtin_floorf(p.x), (int)__builtin_floorf(p.y), (int)__builtin_floorf(p.z)}; }
+
+VRT_DEV bool in_world(const KArgs &a, I3 p) {  // comp:224-226
+    return p.x >= a.wmin[0] && p.y >= a.wmin[1] && p.z >= a.wmin[2] &&
+           p.x < a.wmax[0] && p.y < a.wmax[1] && p.z < a.wmax[2];
+}
+
+// Leaf record words (vrt_layout.h): w0 = R | G<<8 | B<<16 | alpha<<24, w1 = refr | illum<<8 | k<<16;
+// 0/0 stands for empty space (the shader's zeroed VoxelData).
+VRT_DEV float refraction_of(uint32_t w1) { return ((float)(w1 & 0xffu) / 255.0f) * 3.0f; }  // comp:126-128,177
+
+struct Hit {
+    I3 map;           // hitMapPos
+    F3 point;         // hitPoint
+    F3 normal;        // hitNormal
+    uint32_t p0, p1;  // prevVoxel leaf words
+    uint32_t h0, h1;  // hitVoxel leaf words
+};
+
+// exp() convention shared with the oracle (Cephes-style, plain mul/add)
+VRT_DEV float det_expf(float x) {
+    if (x > 88.0f) return __builtin_huge_valf();
+    if (x < -87.0f) return 0.0f;
+    float k = __builtin_rintf(x * 1.44269504088896341f);
+    float r = x - k * 0.693359375f;
+    r = r - k * -2.12194440e-4f;
+    float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    p = p * z + r;
+    p = p + 1.0f;
+    int ki = (int)k;
+    return p * __uint_as_float((uint32_t)(ki + 127) << 23);
+}
+
+VRT_DEV int face_index(F3 n) {  // comp:419-433
+    if (len3(n) < 0.5f) return 0;
+    float ax = __builtin_fabsf(n.x), ay = __builtin_fabsf(n.y), az = __builtin_fabsf(n.z);
+    if (ax > ay && ax > az) return n.x > 0.0f ? 0 : 1;
+    else if (ay > az) return n.y > 0.0f ? 2 : 3;
+    else return n.z > 0.0f ? 4 : 5;
+}
+
+VRT_DEV uint32_t unorm8(float v) {  // rgba8 imageStore: clamp, scale, round to nearest even
+    float c = fmin_c(fmax_c(v, 0.0f), 1.0f);
+    return (uint32_t)__builtin_rintf(c * 255.0f);
+}
+
+VRT_DEV void mat_vec(const float *m, float x, float y, float z, float w, float out[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = (m[0 * 4 + r] * x + m[1 * 4 + r] * y) + (m[2 * 4 + r] * z + m[3 * 4 + r] * w);
+}
+
+struct Decoded { float c[4]; float p[3]; };
+VRT_DEV Decoded decode_leaf(uint32_t w0, uint32_t w1) {  // comp:173-178
+    Decoded d;
+    d.c[0] = (float)(w0 & 0xffu) / 255.0f;
+    d.c[1] = (float)((w0 >> 8) & 0xffu) / 255.0f;
+    d.c[2] = (float)((w0 >> 16) & 0xffu) / 255.0f;
+    d.c[3] = (float)(w0 >> 24) / 255.0f;
+    d.p[0] = ((float)(w1 & 0xffu) / 255.0f) * 3.0f;
+    d.p[1] = (float)((w1 >> 8) & 0xffu) / 255.0f;
+    d.p[2] = (float)((w1 >> 16) & 0xffu) / 255.0f;
+    return d;
+}
+
+// One pixel: ray generation (comp:624-641), primary-ray pathTrace, packing of the two outputs.
+// TRAV supplies the traversal: eye_medium(), march(), shadow(). MODE: 0 primary, 1 primary + shadow ray.
+template <int MODE, class TRAV>
+VRT_DEV void trace_pixel(const KArgs &a, const typename TRAV::Ctx &tc_, int px, int py, uint32_t &rgba, int2 &idd) {
+    const float kPI = 3.14159265359f;
+    float u = ((float)px / (float)a.width) * 2.0f - 1.0f;
+    float v = ((float)py / (float)a.height) * 2.0f - 1.0f;
+    float view[4];
+    mat_vec(a.inv_proj, u, v, -1.0f, 1.0f, view);
+    if (__builtin_fabsf(view[3]) > 1e-6f) { float w = view[3]; view[0] = view[0] / w; view[1] = view[1] / w; view[2] = view[2] / w; view[3] = view[3] / w; }
+    F3 vd = normalize3(F3{view[0], view[1], view[2]});
+    float wd4[4];
+    mat_vec(a.inv_view, vd.x, vd.y, vd.z, 0.0f, wd4);
+    F3 ray_dir = normalize3(F3{wd4[0], wd4[1], wd4[2]});
+    F3 ray_origin{a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]};
+
+    int voxel_id = 0;
+    int pixel_dist = a.wmax[0] - a.wmin[0];
+    F3 gro = scale3(ray_origin, a.voxel_scale);
+    // medium at the eye (comp:445-449)
+    uint32_t e0, e1;
+    TRAV::eye_medium(a, tc_, floor_i3(gro), e0, e1);
+    Decoded tvd = decode_leaf(e0, e1);
+    float start_iof = (tvd.p[0] > 0.0f && tvd.p[0] < 3.0f) ? tvd.p[0] : 1.0f;
+    float inv_len = 1.0f / __builtin_sqrtf(dot3(ray_dir, ray_dir));
+    ray_dir = scale3(ray_dir, inv_len);
+    float medium_density = tvd.c[3] * 5.0f;
+    float mc[3] = {1.0f, 1.0f, 1.0f};
+    if (tvd.c[3] > 0.0f) { mc[0] = tvd.c[0]; mc[1] = tvd.c[1]; mc[2] = tvd.c[2]; }
+    float tc[3] = {a.global_light[0], a.global_light[1], a.global_light[2]};
+    float fc[3] = {0.0f, 0.0f, 0.0f};
+    const float sky[3] = {0.5f, 0.7f, 1.0f};
+
+    Hit h;
+    bool hit = TRAV::march(a, tc_, gro, ray_dir, start_iof, h);
+    if (!hit) {
+        // distanceInMedium is still 0 here, so the absorption branch (comp:482) cannot fire
+#pragma unroll
+        for (int k = 0; k < 3; ++k) fc[k] = fc[k] + a.global_light[k] * sky[k] * tc[k] * 1.0f;
+    } else {
+        F3 normal = h.normal;
+        if (!(len3(h.normal) > 0.0f)) normal = F3{0.0f, 1.0f, 0.0f};
+        F3 hpw{h.point.x / a.voxel_scale, h.point.y / a.voxel_scale, h.point.z / a.voxel_scale};
+        float dist_in_medium = 0.0f + len3(sub3(hpw, gro)) / a.voxel_scale;
+        Decoded hv = decode_leaf(h.h0, h.h1);
+        Decoded lv = decode_leaf(h.p0, h.p1);
+        if (hv.c[3] <= 0.0f) { hv.p[0] = 1.0f; hv.p[1] = 0.0f; hv.p[2] = 0.0f; }
+        if (lv.c[3] <= 0.0f) {
+            if (start_iof > 0.0f) { lv.p[0] = 0.0f; lv.p[1] = 0.0f; lv.p[2] = 0.0f; }
+            else { lv.p[0] = 1.0f; lv.p[1] = 0.0f; lv.p[2] = 0.0f; }
+        }
+        float sc[4];
+        if (hv.c[3] > 0.0f) { sc[0] = hv.c[0]; sc[1] = hv.c[1]; sc[2] = hv.c[2]; sc[3] = hv.c[3]; }
+        else { sc[0] = lv.c[0]; sc[1] = lv.c[1]; sc[2] = lv.c[2]; sc[3] = lv.c[3]; }
+        if (dist_in_medium > 1e-6f && medium_density > 0.0f) {  // comp:512-516
+            float kk = -medium_density * dist_in_medium;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) tc[k] = tc[k] * det_expf(kk * (1.0f - mc[k]));
+        }
+        if (h.map.x == a.highlighted[0] && h.map.y == a.highlighted[1] && h.map.z == a.highlighted[2]) {
+            sc[0] = 1.0f - sc[0]; sc[1] = 1.0f - sc[1]; sc[2] = 1.0f - sc[2]; sc[3] = 1.0f;
+        }
+        float cosi = dot3(ray_dir, normal);
+        if (cosi > 0.0f) normal = F3{-normal.x, -normal.y, -normal.z};
+        F3 light{a.light_dir[0], a.light_dir[1], a.light_dir[2]};
+        float ndotl = fmax_c(dot3(normal, light), 0.0f);
+        if (sc[3] >= 1.0f) {  // depth 0, first hit (comp:539-544)
+            int lin = h.map.x + a.tex_dim * (h.map.y + a.tex_dim * h.map.z);
+            voxel_id = lin * 6 + face_index(h.normal);
+            pixel_dist = (int)len3(sub3(hpw, ray_origin));
+        }
+        if (sc[3] < 1.0f) {  // translucent first hit: direct-lit fallback (comp:548-553)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float direct = a.global_light[k] * ndotl;
+                float lit = sc[k] * direct;
+                fc[k] = fc[k] + tc[k] * lit * 1.0f;
+            }
+        } else {
+            float emission = hv.p[1] * 10.0f;
+            if (emission > 0.0f) {  // comp:575-578
+#pragma unroll
+                for (int k = 0; k < 3; ++k) fc[k] = fc[k] + tc[k] * sc[k] * emission * 1.0f;
+            } else {
+                int lit = 1;
+                if (MODE == 1) lit = TRAV::shadow(a, tc_, add3(h.point, scale3(normal, 2e-3f)), light);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    float direct = a.global_light[k] * (float)lit * ndotl;
+                    fc[k] = fc[k] + direct * sc[k] * tc[k] * 1.0f / kPI;
+                }
+            }
+        }
+    }
+    rgba = unorm8(fc[0]) | (unorm8(fc[1]) << 8) | (unorm8(fc[2]) << 16) | (255u << 24);
+    idd = make_int2(voxel_id, pixel_dist);
+}
+
+// One lane per pixel; a wave covers a TW x TH pixel tile (TW*TH == 64) so the 64 rays of a wave
+// stay spatially coherent; workgroups walk tiles with a grid-stride loop.
+template <int MODE, class TRAV, int TW, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void trace_kernel(const KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint2 lds_dyn[];
+    constexpr int TH = 64 / TW;
+    constexpr int WAVES = BLOCK / 64;
+    typename TRAV::Ctx tc_;
+    TRAV::template block_init<BLOCK>(a, lds_dyn, tc_);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int tiles_x = (a.width + TW - 1) / TW;
+    const int tiles_y = (a.n_rows + TH - 1) / TH;
+    const int n_tiles = tiles_x * tiles_y;
+    const int lx = lane % TW, ly = lane / TW;
+    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
+        int tx = tile % tiles_x, ty = tile / tiles_x;
+        int px = tx * TW + lx;
+        int j = ty * TH + ly;
+        if (px < a.width && j < a.n_rows) {
+            int py = a.row0 + (j / a.tile_rows) * a.row_stride + (j % a.tile_rows);
+            uint32_t rgba;
+            int2 idd;
+            trace_pixel<MODE, TRAV>(a, tc_, px, py, rgba, idd);
+            size_t o = (size_t)(a.compact ? j : py) * (size_t)a.width + (size_t)px;
+            if (a.out_rgba) a.out_rgba[o] = rgba;
+            if (a.out_id) a.out_id[o] = idd;
+        }
+    }
+}
+
+// exactness probe for the arithmetic contract: out[i] = op(x[i], y[i])
+__global__ void math_probe_kernel(int op, const float *x, const float *y, float *out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = x[i], b = y[i], r = 0.0f;
+    switch (op) {
+        case 0: r = a / b; break;
+        case 1: r = __builtin_sqrtf(a); break;
+        case 2: r = 1.0f / __builtin_sqrtf(a); break;
+        case 3: r = __builtin_floorf(a); break;
+        case 4: r = __builtin_rintf(a); break;
+        case 5: r = a * b + 1.0f; break;          // must NOT be fused
+        case 6: r = det_expf(a); break;
+        case 7: r = (float)(int)a; break;
+        case 8: r = a + b; break;
+        case 9: r = a * b; break;
+        default: break;
+    }
+    out[i] = r;
+}
+
+}  // namespace vrt

@@ -1,69 +1,16 @@
-// vrt_kernels.hip.h -- gfx950 ray-casting kernels (device code only).
-//
-// What the reference computes per pixel in shaders/raytracing.comp (main :624-645,
-// pathTrace :435-622, hitMarching :248-330, octreeFind :137-220, notInShadow
-// :333-377) is evaluated here by one lane per pixel over a level-ordered array
-// of 8-byte node records (see vrt_layout.h), not over the RGBA8UI texel volume.
-//
-// Arithmetic contract (must hold bit-for-bit against the CPU oracle):
-//   * IEEE binary32, round-to-nearest-even, NO contraction (-ffp-contract=off),
-//     correctly rounded '/' and sqrtf (hipcc default), denormals kept.
-//   * mat4*vec4 = (m0*x + m1*y) + (m2*z + m3*w); dot3 = (x*x' + y*y') + z*z';
-//     normalize(v) = v * (1/sqrt(dot(v,v))); min(a,b) = b<a?b:a; max(a,b) = a<b?b:a.
-//   * The DDA advances one octree NODE per step exactly as hitMarching does; the
-//     node lookup is free to use any structure because octreeFind's result is a
-//     pure function of the query point (deepest node containing it).
+// vrt_kernels_v1.hip.h -- traversal variant "v1": the straightforward form.
+// octreeFind (comp:137-220) with explicit integer AABBs per level and a single
+// cached parent, restarting at the root whenever the point leaves it -- the
+// shader's own strategy over the 8-byte record layout. Kept as the measured
+// baseline the tuned traversal (vrt_kernels.hip.h) is compared against.
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "vrt_common.hip.h"
 
 namespace vrt {
+namespace v1 {
 
-struct F3 { float x, y, z; };
-struct I3 { int x, y, z; };
-
-// Kernel arguments: passed by value (kernarg segment -> scalar loads, wave-uniform).
-struct KArgs {
-    float inv_proj[16];
-    float inv_view[16];
-    float cam_pos[4];
-    float voxel_scale;
-    int wmin[3];
-    int wmax[3];
-    float global_light[4];
-    float light_dir[3];
-    int highlighted[3];
-    int tex_dim;
-    int width, height;
-    // rows traced by this launch: local row j in [0, n_rows) maps to frame row
-    //   y = row0 + (j / tile_rows) * row_stride + (j % tile_rows)
-    int row0, n_rows, tile_rows, row_stride;
-    int compact;              // 1: outputs indexed by local row j, 0: by frame row y
-    const uint2 *nodes;       // level-ordered records, root = record 0
-    uint32_t n_records;
-    uint32_t lds_records;     // prefix of `nodes` staged in LDS by each workgroup
-    uint32_t *out_rgba;       // packed R | G<<8 | B<<16 | A<<24
-    int2 *out_id;             // (voxelID, dist)
-};
-
-#define VRT_DEV __device__ __forceinline__
-
-VRT_DEV float fmin_c(float a, float b) { return b < a ? b : a; }
-VRT_DEV float fmax_c(float a, float b) { return a < b ? b : a; }
-VRT_DEV float dot3(F3 a, F3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-VRT_DEV float len3(F3 a) { return __builtin_sqrtf(dot3(a, a)); }
-VRT_DEV F3 scale3(F3 a, float s) { return F3{a.x * s, a.y * s, a.z * s}; }
-VRT_DEV F3 add3(F3 a, F3 b) { return F3{a.x + b.x, a.y + b.y, a.z + b.z}; }
-VRT_DEV F3 sub3(F3 a, F3 b) { return F3{a.x - b.x, a.y - b.y, a.z - b.z}; }
-VRT_DEV F3 normalize3(F3 a) { return scale3(a, 1.0f / __builtin_sqrtf(dot3(a, a))); }
-VRT_DEV float sign_c(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
-VRT_DEV float comp(F3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
-
-// Record words (vrt_layout.h):
-//   internal: w0 = child_mask | leaf_mask << 8, w1 = index of first child record
-//   leaf    : w0 = R | G<<8 | B<<16 | alpha<<24, w1 = refr | illum<<8 | k<<16
 struct Parent {            // the cached internal node (octreeFind's inout state, comp:137)
-    uint32_t masks, base;
+    uint32_t masks, base;  // w0 = child_mask | leaf_mask << 8, w1 = index of first child record
     I3 mn, mx;
 };
 struct Found {             // deepest node containing the query point
@@ -72,357 +19,149 @@ struct Found {             // deepest node containing the query point
 };
 
 template <bool USE_LDS>
-VRT_DEV uint2 load_record(const KArgs &a, const uint2 *lds, uint32_t idx) {
-    if (USE_LDS) {
-        if (idx < a.lds_records) return lds[idx];
+struct Trav {
+    struct Ctx {
+        const uint2 *lds;
+        uint2 root;
+    };
+
+    template <int BLOCK>
+    static VRT_DEV void block_init(const KArgs &a, uint2 *lds_dyn, Ctx &c) {
+        if (USE_LDS) {
+            for (uint32_t i = threadIdx.x; i < a.lds_records; i += BLOCK) lds_dyn[i] = a.nodes[i];
+            __syncthreads();
+        }
+        c.lds = lds_dyn;
+        c.root = a.nodes[0];
     }
-    return a.nodes[idx];
-}
 
-VRT_DEV bool in_world(const KArgs &a, I3 p) {
-    return p.x >= a.wmin[0] && p.y >= a.wmin[1] && p.z >= a.wmin[2] &&
-           p.x < a.wmax[0] && p.y < a.wmax[1] && p.z < a.wmax[2];
-}
+    static VRT_DEV uint2 load_record(const KArgs &a, const Ctx &c, uint32_t idx) {
+        if (USE_LDS) {
+            if (idx < a.lds_records) return c.lds[idx];
+        }
+        return a.nodes[idx];
+    }
 
-// octreeFind (comp:137-220). Restarts at the cached parent when it still
-// contains the point, else at the root; on return `par` is the parent of the
-// node found, as in the shader.
-template <bool USE_LDS>
-VRT_DEV Found find_node(const KArgs &a, const uint2 *lds, I3 p, Parent &par, uint2 root) {
-    Found f;
-    f.w0 = 0u; f.w1 = 0u;
-    if (!in_world(a, p)) { // comp:143-145 (bounds are implementation-undefined there; convention C8)
-        f.mn = I3{a.wmin[0], a.wmin[1], a.wmin[2]};
-        f.mx = I3{a.wmax[0], a.wmax[1], a.wmax[2]};
+    static VRT_DEV Parent root_parent(const KArgs &a, const Ctx &c) {
+        Parent p;
+        p.masks = c.root.x; p.base = c.root.y;
+        p.mn = I3{a.wmin[0], a.wmin[1], a.wmin[2]};
+        p.mx = I3{a.wmax[0], a.wmax[1], a.wmax[2]};
+        return p;
+    }
+
+    // On return `par` is the parent of the node found, as in the shader.
+    static VRT_DEV Found find_node(const KArgs &a, const Ctx &c, I3 p, Parent &par) {
+        Found f;
+        f.w0 = 0u; f.w1 = 0u;
+        if (!in_world(a, p)) {  // comp:143-145 (bounds are implementation-undefined there; convention C8)
+            f.mn = I3{a.wmin[0], a.wmin[1], a.wmin[2]};
+            f.mx = I3{a.wmax[0], a.wmax[1], a.wmax[2]};
+            return f;
+        }
+        bool inside = p.x >= par.mn.x && p.y >= par.mn.y && p.z >= par.mn.z &&
+                      p.x < par.mx.x && p.y < par.mx.y && p.z < par.mx.z;
+        if (!inside) par = root_parent(a, c);
+        for (int i = 0; i < 16; ++i) {
+            int mx_ = par.mn.x + ((par.mx.x - par.mn.x) >> 1);  // extents are >= 0: >>1 == /2
+            int my_ = par.mn.y + ((par.mx.y - par.mn.y) >> 1);
+            int mz_ = par.mn.z + ((par.mx.z - par.mn.z) >> 1);
+            bool hx = p.x >= mx_, hy = p.y >= my_, hz = p.z >= mz_;
+            uint32_t ci = (hx ? 4u : 0u) | (hy ? 2u : 0u) | (hz ? 1u : 0u);
+            I3 cmn{hx ? mx_ : par.mn.x, hy ? my_ : par.mn.y, hz ? mz_ : par.mn.z};
+            I3 cmx{hx ? par.mx.x : mx_, hy ? par.mx.y : my_, hz ? par.mx.z : mz_};
+            uint32_t bit = 1u << ci;
+            if (!(par.masks & bit)) { f.mn = cmn; f.mx = cmx; return f; }  // absent child: empty space
+            uint32_t idx = par.base + (uint32_t)__builtin_popcount(par.masks & 0xffu & (bit - 1u));
+            uint2 rec = load_record(a, c, idx);
+            if (par.masks & (bit << 8)) { f.w0 = rec.x; f.w1 = rec.y; f.mn = cmn; f.mx = cmx; return f; }
+            par.masks = rec.x; par.base = rec.y; par.mn = cmn; par.mx = cmx;
+        }
+        f.mn = par.mn; f.mx = par.mx;  // unreachable for trees the uploader accepts (depth <= 15)
         return f;
     }
-    bool inside = p.x >= par.mn.x && p.y >= par.mn.y && p.z >= par.mn.z &&
-                  p.x < par.mx.x && p.y < par.mx.y && p.z < par.mx.z;
-    if (!inside) {
-        par.masks = root.x; par.base = root.y;
-        par.mn = I3{a.wmin[0], a.wmin[1], a.wmin[2]};
-        par.mx = I3{a.wmax[0], a.wmax[1], a.wmax[2]};
-    }
-    for (int i = 0; i < 16; ++i) {
-        int mx_ = par.mn.x + ((par.mx.x - par.mn.x) >> 1);  // extents are >= 0: >>1 == /2
-        int my_ = par.mn.y + ((par.mx.y - par.mn.y) >> 1);
-        int mz_ = par.mn.z + ((par.mx.z - par.mn.z) >> 1);
-        bool hx = p.x >= mx_, hy = p.y >= my_, hz = p.z >= mz_;
-        uint32_t ci = (hx ? 4u : 0u) | (hy ? 2u : 0u) | (hz ? 1u : 0u);
-        I3 cmn{hx ? mx_ : par.mn.x, hy ? my_ : par.mn.y, hz ? mz_ : par.mn.z};
-        I3 cmx{hx ? par.mx.x : mx_, hy ? par.mx.y : my_, hz ? par.mx.z : mz_};
-        uint32_t bit = 1u << ci;
-        if (!(par.masks & bit)) { f.mn = cmn; f.mx = cmx; return f; }  // absent child: empty space
-        uint32_t idx = par.base + (uint32_t)__builtin_popcount(par.masks & 0xffu & (bit - 1u));
-        uint2 rec = load_record<USE_LDS>(a, lds, idx);
-        if (par.masks & (bit << 8)) { f.w0 = rec.x; f.w1 = rec.y; f.mn = cmn; f.mx = cmx; return f; }
-        par.masks = rec.x; par.base = rec.y; par.mn = cmn; par.mx = cmx;
-    }
-    // unreachable for trees the uploader accepts (depth <= 15): treated as empty
-    f.mn = par.mn; f.mx = par.mx;
-    return f;
-}
 
-VRT_DEV float refraction_of(uint32_t w1) { return ((float)(w1 & 0xffu) / 255.0f) * 3.0f; } // comp:126-128,177
-VRT_DEV I3 floor_i3(F3 p) { return I3{(int)__builtin_floorf(p.x), (int)__builtin_floorf(p.y), (int)__builtin_floorf(p.z)}; }
+    static VRT_DEV void eye_medium(const KArgs &a, const Ctx &c, I3 p, uint32_t &w0, uint32_t &w1) {
+        Parent par = root_parent(a, c);
+        Found f = find_node(a, c, p, par);
+        w0 = f.w0; w1 = f.w1;
+    }
 
-struct Hit {
-    I3 map;        // hitMapPos
-    F3 point;      // hitPoint
-    F3 normal;     // hitNormal
-    uint32_t p0, p1;  // prevVoxel leaf words
-    uint32_t h0, h1;  // hitVoxel leaf words
+    // hitMarching (comp:248-330)
+    static VRT_DEV bool march(const KArgs &a, const Ctx &c, F3 origin, F3 dir, float ray_iof, Hit &h) {
+        F3 rp = origin;
+        float inv_len = 1.0f / __builtin_sqrtf(dot3(dir, dir));
+        dir = scale3(dir, inv_len);
+        F3 inv;
+        inv.x = (__builtin_fabsf(dir.x) < 1e-8f) ? 1e20f : 1.0f / dir.x;
+        inv.y = (__builtin_fabsf(dir.y) < 1e-8f) ? 1e20f : 1.0f / dir.y;
+        inv.z = (__builtin_fabsf(dir.z) < 1e-8f) ? 1e20f : 1.0f / dir.z;
+        Parent par = root_parent(a, c);
+        I3 mp = floor_i3(rp);
+        Found cur = find_node(a, c, mp, par);
+        // medium the ray is currently in: refraction index if (alpha > 0 && props[0] > 0)
+        float cur_ref = refraction_of(cur.w1);
+        bool cur_solid = (cur.w0 >> 24) != 0u && cur_ref > 0.0f;
+        h.normal = F3{0.0f, 0.0f, 0.0f};
+        for (int i = 0; i < 1024; ++i) {
+            F3 tp;
+            tp.x = (dir.x > 0.0f ? (float)cur.mx.x : (float)cur.mn.x) - rp.x;
+            tp.y = (dir.y > 0.0f ? (float)cur.mx.y : (float)cur.mn.y) - rp.y;
+            tp.z = (dir.z > 0.0f ? (float)cur.mx.z : (float)cur.mn.z) - rp.z;
+            float tx = tp.x * inv.x, ty = tp.y * inv.y, tz = tp.z * inv.z;
+            float t = fmin_c(tx, fmin_c(ty, tz));
+            int axis = (tx < ty) ? ((tx < tz) ? 0 : 2) : ((ty < tz) ? 1 : 2);
+            float sd = sign_c(comp(dir, axis));
+            float n = -sd;
+            h.normal = F3{axis == 0 ? n : 0.0f, axis == 1 ? n : 0.0f, axis == 2 ? n : 0.0f};
+            rp.x = rp.x + dir.x * t; rp.y = rp.y + dir.y * t; rp.z = rp.z + dir.z * t;
+            float push = sd * 0.0001f;
+            if (axis == 0) rp.x = rp.x + push; else if (axis == 1) rp.y = rp.y + push; else rp.z = rp.z + push;
+            mp = floor_i3(rp);
+            if (!in_world(a, mp)) return false;
+            uint32_t pw0 = cur.w0, pw1 = cur.w1;
+            float prev_ref = cur_solid ? cur_ref : ray_iof;
+            cur = find_node(a, c, mp, par);
+            cur_ref = refraction_of(cur.w1);
+            cur_solid = (cur.w0 >> 24) != 0u && cur_ref > 0.0f;
+            float now_ref = cur_solid ? cur_ref : 1.0f;
+            if (__builtin_fabsf(now_ref - prev_ref) > 0.0001f) {
+                h.map = mp; h.point = rp; h.p0 = pw0; h.p1 = pw1; h.h0 = cur.w0; h.h1 = cur.w1;
+                return true;
+            }
+        }
+        return false;
+    }
+
+    // notInShadow (comp:333-377); the light direction is used as given
+    static VRT_DEV int shadow(const KArgs &a, const Ctx &c, F3 origin, F3 ld) {
+        F3 rp = origin, inv;
+        inv.x = (__builtin_fabsf(ld.x) < 1e-8f) ? 1e20f : 1.0f / ld.x;
+        inv.y = (__builtin_fabsf(ld.y) < 1e-8f) ? 1e20f : 1.0f / ld.y;
+        inv.z = (__builtin_fabsf(ld.z) < 1e-8f) ? 1e20f : 1.0f / ld.z;
+        I3 mp = floor_i3(rp);
+        Parent par = root_parent(a, c);
+        for (int i = 0; i < 64; ++i) {
+            Found v = find_node(a, c, mp, par);
+            float alpha = (float)(v.w0 >> 24) / 255.0f;
+            // properties[1] == 0  <=>  illumination byte == 0
+            if (alpha > 0.1f && ((v.w1 >> 8) & 0xffu) == 0u) return 0;
+            F3 tp;
+            tp.x = (ld.x > 0.0f ? (float)v.mx.x : (float)v.mn.x) - rp.x;
+            tp.y = (ld.y > 0.0f ? (float)v.mx.y : (float)v.mn.y) - rp.y;
+            tp.z = (ld.z > 0.0f ? (float)v.mx.z : (float)v.mn.z) - rp.z;
+            float tx = tp.x * inv.x, ty = tp.y * inv.y, tz = tp.z * inv.z;
+            float t = fmin_c(tx, fmin_c(ty, tz));
+            int axis = (tx < ty) ? ((tx < tz) ? 0 : 2) : ((ty < tz) ? 1 : 2);
+            rp.x = rp.x + ld.x * t; rp.y = rp.y + ld.y * t; rp.z = rp.z + ld.z * t;
+            float push = sign_c(comp(ld, axis)) * 0.001f;
+            if (axis == 0) rp.x = rp.x + push; else if (axis == 1) rp.y = rp.y + push; else rp.z = rp.z + push;
+            mp = floor_i3(rp);
+            if (!in_world(a, mp)) return 1;
+        }
+        return 1;
+    }
 };
 
-// hitMarching (comp:248-330)
-template <bool USE_LDS>
-VRT_DEV bool march(const KArgs &a, const uint2 *lds, uint2 root, F3 origin, F3 dir, float ray_iof, Hit &h) {
-    F3 rp = origin;
-    float inv_len = 1.0f / __builtin_sqrtf(dot3(dir, dir));
-    dir = scale3(dir, inv_len);
-    F3 inv;
-    inv.x = (__builtin_fabsf(dir.x) < 1e-8f) ? 1e20f : 1.0f / dir.x;
-    inv.y = (__builtin_fabsf(dir.y) < 1e-8f) ? 1e20f : 1.0f / dir.y;
-    inv.z = (__builtin_fabsf(dir.z) < 1e-8f) ? 1e20f : 1.0f / dir.z;
-    Parent par;
-    par.masks = root.x; par.base = root.y;
-    par.mn = I3{a.wmin[0], a.wmin[1], a.wmin[2]};
-    par.mx = I3{a.wmax[0], a.wmax[1], a.wmax[2]};
-    I3 mp = floor_i3(rp);
-    Found cur = find_node<USE_LDS>(a, lds, mp, par, root);
-    // medium the ray is currently in: refraction index if (alpha > 0 && props[0] > 0)
-    float cur_ref = refraction_of(cur.w1);
-    bool cur_solid = (cur.w0 >> 24) != 0u && cur_ref > 0.0f;
-    h.normal = F3{0.0f, 0.0f, 0.0f};
-    for (int i = 0; i < 1024; ++i) {
-        F3 tp;
-        tp.x = (dir.x > 0.0f ? (float)cur.mx.x : (float)cur.mn.x) - rp.x;
-        tp.y = (dir.y > 0.0f ? (float)cur.mx.y : (float)cur.mn.y) - rp.y;
-        tp.z = (dir.z > 0.0f ? (float)cur.mx.z : (float)cur.mn.z) - rp.z;
-        float tx = tp.x * inv.x, ty = tp.y * inv.y, tz = tp.z * inv.z;
-        float t = fmin_c(tx, fmin_c(ty, tz));
-        int axis = (tx < ty) ? ((tx < tz) ? 0 : 2) : ((ty < tz) ? 1 : 2);
-        float sd = sign_c(comp(dir, axis));
-        float n = -sd;
-        h.normal = F3{axis == 0 ? n : 0.0f, axis == 1 ? n : 0.0f, axis == 2 ? n : 0.0f};
-        rp.x = rp.x + dir.x * t; rp.y = rp.y + dir.y * t; rp.z = rp.z + dir.z * t;
-        float push = sd * 0.0001f;
-        if (axis == 0) rp.x = rp.x + push; else if (axis == 1) rp.y = rp.y + push; else rp.z = rp.z + push;
-        mp = floor_i3(rp);
-        if (!in_world(a, mp)) return false;
-        uint32_t pw0 = cur.w0, pw1 = cur.w1;
-        float prev_ref = cur_solid ? cur_ref : ray_iof;
-        cur = find_node<USE_LDS>(a, lds, mp, par, root);
-        cur_ref = refraction_of(cur.w1);
-        cur_solid = (cur.w0 >> 24) != 0u && cur_ref > 0.0f;
-        float now_ref = cur_solid ? cur_ref : 1.0f;
-        if (__builtin_fabsf(now_ref - prev_ref) > 0.0001f) {
-            h.map = mp; h.point = rp; h.p0 = pw0; h.p1 = pw1; h.h0 = cur.w0; h.h1 = cur.w1;
-            return true;
-        }
-    }
-    return false;
-}
-
-// notInShadow (comp:333-377); the light direction is used as given
-template <bool USE_LDS>
-VRT_DEV int not_in_shadow(const KArgs &a, const uint2 *lds, uint2 root, F3 origin, F3 ld) {
-    F3 rp = origin, inv;
-    inv.x = (__builtin_fabsf(ld.x) < 1e-8f) ? 1e20f : 1.0f / ld.x;
-    inv.y = (__builtin_fabsf(ld.y) < 1e-8f) ? 1e20f : 1.0f / ld.y;
-    inv.z = (__builtin_fabsf(ld.z) < 1e-8f) ? 1e20f : 1.0f / ld.z;
-    I3 mp = floor_i3(rp);
-    Parent par;
-    par.masks = root.x; par.base = root.y;
-    par.mn = I3{a.wmin[0], a.wmin[1], a.wmin[2]};
-    par.mx = I3{a.wmax[0], a.wmax[1], a.wmax[2]};
-    for (int i = 0; i < 64; ++i) {
-        Found v = find_node<USE_LDS>(a, lds, mp, par, root);
-        float alpha = (float)(v.w0 >> 24) / 255.0f;
-        // properties[1] == 0  <=>  illumination byte == 0
-        if (alpha > 0.1f && ((v.w1 >> 8) & 0xffu) == 0u) return 0;
-        F3 tp;
-        tp.x = (ld.x > 0.0f ? (float)v.mx.x : (float)v.mn.x) - rp.x;
-        tp.y = (ld.y > 0.0f ? (float)v.mx.y : (float)v.mn.y) - rp.y;
-        tp.z = (ld.z > 0.0f ? (float)v.mx.z : (float)v.mn.z) - rp.z;
-        float tx = tp.x * inv.x, ty = tp.y * inv.y, tz = tp.z * inv.z;
-        float t = fmin_c(tx, fmin_c(ty, tz));
-        int axis = (tx < ty) ? ((tx < tz) ? 0 : 2) : ((ty < tz) ? 1 : 2);
-        rp.x = rp.x + ld.x * t; rp.y = rp.y + ld.y * t; rp.z = rp.z + ld.z * t;
-        float push = sign_c(comp(ld, axis)) * 0.001f;
-        if (axis == 0) rp.x = rp.x + push; else if (axis == 1) rp.y = rp.y + push; else rp.z = rp.z + push;
-        mp = floor_i3(rp);
-        if (!in_world(a, mp)) return 1;
-    }
-    return 1;
-}
-
-// exp() convention shared with the oracle (Cephes-style, plain mul/add)
-VRT_DEV float det_expf(float x) {
-    if (x > 88.0f) return __builtin_huge_valf();
-    if (x < -87.0f) return 0.0f;
-    float k = __builtin_rintf(x * 1.44269504088896341f);
-    float r = x - k * 0.693359375f;
-    r = r - k * -2.12194440e-4f;
-    float z = r * r;
-    float p = 1.9875691500e-4f;
-    p = p * r + 1.3981999507e-3f;
-    p = p * r + 8.3334519073e-3f;
-    p = p * r + 4.1665795894e-2f;
-    p = p * r + 1.6666665459e-1f;
-    p = p * r + 5.0000001201e-1f;
-    p = p * z + r;
-    p = p + 1.0f;
-    int ki = (int)k;
-    return p * __uint_as_float((uint32_t)(ki + 127) << 23);
-}
-
-VRT_DEV int face_index(F3 n) { // comp:419-433
-    if (len3(n) < 0.5f) return 0;
-    float ax = __builtin_fabsf(n.x), ay = __builtin_fabsf(n.y), az = __builtin_fabsf(n.z);
-    if (ax > ay && ax > az) return n.x > 0.0f ? 0 : 1;
-    else if (ay > az) return n.y > 0.0f ? 2 : 3;
-    else return n.z > 0.0f ? 4 : 5;
-}
-
-VRT_DEV uint32_t unorm8(float v) {
-    float c = fmin_c(fmax_c(v, 0.0f), 1.0f);
-    return (uint32_t)__builtin_rintf(c * 255.0f);
-}
-
-VRT_DEV void mat_vec(const float *m, float x, float y, float z, float w, float out[4]) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) out[r] = (m[0 * 4 + r] * x + m[1 * 4 + r] * y) + (m[2 * 4 + r] * z + m[3 * 4 + r] * w);
-}
-
-struct Decoded { float c[4]; float p[3]; };
-VRT_DEV Decoded decode_leaf(uint32_t w0, uint32_t w1) { // comp:173-178
-    Decoded d;
-    d.c[0] = (float)(w0 & 0xffu) / 255.0f;
-    d.c[1] = (float)((w0 >> 8) & 0xffu) / 255.0f;
-    d.c[2] = (float)((w0 >> 16) & 0xffu) / 255.0f;
-    d.c[3] = (float)(w0 >> 24) / 255.0f;
-    d.p[0] = ((float)(w1 & 0xffu) / 255.0f) * 3.0f;
-    d.p[1] = (float)((w1 >> 8) & 0xffu) / 255.0f;
-    d.p[2] = (float)((w1 >> 16) & 0xffu) / 255.0f;
-    return d;
-}
-
-// pathTrace restricted to the primary ray (+ optional shadow ray): comp:435-497,
-// 522-544, 573-589, 619-621. MODE: 0 primary, 1 primary + shadow.
-template <int MODE, bool USE_LDS>
-VRT_DEV void trace_pixel(const KArgs &a, const uint2 *lds, uint2 root, int px, int py, uint32_t &rgba, int2 &idd) {
-    const float kPI = 3.14159265359f;
-    float u = ((float)px / (float)a.width) * 2.0f - 1.0f;
-    float v = ((float)py / (float)a.height) * 2.0f - 1.0f;
-    float view[4];
-    mat_vec(a.inv_proj, u, v, -1.0f, 1.0f, view);
-    if (__builtin_fabsf(view[3]) > 1e-6f) { float w = view[3]; view[0] = view[0] / w; view[1] = view[1] / w; view[2] = view[2] / w; view[3] = view[3] / w; }
-    F3 vd = normalize3(F3{view[0], view[1], view[2]});
-    float wd4[4];
-    mat_vec(a.inv_view, vd.x, vd.y, vd.z, 0.0f, wd4);
-    F3 ray_dir = normalize3(F3{wd4[0], wd4[1], wd4[2]});
-    F3 ray_origin{a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]};
-
-    int voxel_id = 0;
-    int pixel_dist = a.wmax[0] - a.wmin[0];
-    F3 gro = scale3(ray_origin, a.voxel_scale);
-    // medium at the eye (comp:445-449)
-    Parent par0;
-    par0.masks = root.x; par0.base = root.y;
-    par0.mn = I3{a.wmin[0], a.wmin[1], a.wmin[2]};
-    par0.mx = I3{a.wmax[0], a.wmax[1], a.wmax[2]};
-    Found tv = find_node<USE_LDS>(a, lds, floor_i3(gro), par0, root);
-    Decoded tvd = decode_leaf(tv.w0, tv.w1);
-    float start_iof = (tvd.p[0] > 0.0f && tvd.p[0] < 3.0f) ? tvd.p[0] : 1.0f;
-    float inv_len = 1.0f / __builtin_sqrtf(dot3(ray_dir, ray_dir));
-    ray_dir = scale3(ray_dir, inv_len);
-    float medium_density = tvd.c[3] * 5.0f;
-    float mc[3] = {1.0f, 1.0f, 1.0f};
-    if (tvd.c[3] > 0.0f) { mc[0] = tvd.c[0]; mc[1] = tvd.c[1]; mc[2] = tvd.c[2]; }
-    float tc[3] = {a.global_light[0], a.global_light[1], a.global_light[2]};
-    float fc[3] = {0.0f, 0.0f, 0.0f};
-    const float sky[3] = {0.5f, 0.7f, 1.0f};
-
-    Hit h;
-    bool hit = march<USE_LDS>(a, lds, root, gro, ray_dir, start_iof, h);
-    if (!hit) {
-        // distanceInMedium is still 0 here, so the absorption branch (comp:482) cannot fire
-#pragma unroll
-        for (int k = 0; k < 3; ++k) fc[k] = fc[k] + a.global_light[k] * sky[k] * tc[k] * 1.0f;
-    } else {
-        F3 normal = h.normal;
-        if (!(len3(h.normal) > 0.0f)) normal = F3{0.0f, 1.0f, 0.0f};
-        F3 hpw{h.point.x / a.voxel_scale, h.point.y / a.voxel_scale, h.point.z / a.voxel_scale};
-        float dist_in_medium = 0.0f + len3(sub3(hpw, gro)) / a.voxel_scale;
-        Decoded hv = decode_leaf(h.h0, h.h1);
-        Decoded lv = decode_leaf(h.p0, h.p1);
-        if (hv.c[3] <= 0.0f) { hv.p[0] = 1.0f; hv.p[1] = 0.0f; hv.p[2] = 0.0f; }
-        if (lv.c[3] <= 0.0f) {
-            if (start_iof > 0.0f) { lv.p[0] = 0.0f; lv.p[1] = 0.0f; lv.p[2] = 0.0f; }
-            else { lv.p[0] = 1.0f; lv.p[1] = 0.0f; lv.p[2] = 0.0f; }
-        }
-        float sc[4];
-        if (hv.c[3] > 0.0f) { sc[0] = hv.c[0]; sc[1] = hv.c[1]; sc[2] = hv.c[2]; sc[3] = hv.c[3]; }
-        else { sc[0] = lv.c[0]; sc[1] = lv.c[1]; sc[2] = lv.c[2]; sc[3] = lv.c[3]; }
-        if (dist_in_medium > 1e-6f && medium_density > 0.0f) { // comp:512-516
-            float kk = -medium_density * dist_in_medium;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) tc[k] = tc[k] * det_expf(kk * (1.0f - mc[k]));
-        }
-        if (h.map.x == a.highlighted[0] && h.map.y == a.highlighted[1] && h.map.z == a.highlighted[2]) {
-            sc[0] = 1.0f - sc[0]; sc[1] = 1.0f - sc[1]; sc[2] = 1.0f - sc[2]; sc[3] = 1.0f;
-        }
-        float cosi = dot3(ray_dir, normal);
-        if (cosi > 0.0f) normal = F3{-normal.x, -normal.y, -normal.z};
-        F3 light{a.light_dir[0], a.light_dir[1], a.light_dir[2]};
-        float ndotl = fmax_c(dot3(normal, light), 0.0f);
-        if (sc[3] >= 1.0f) { // depth 0, first hit (comp:539-544)
-            int lin = h.map.x + a.tex_dim * (h.map.y + a.tex_dim * h.map.z);
-            voxel_id = lin * 6 + face_index(h.normal);
-            pixel_dist = (int)len3(sub3(hpw, ray_origin));
-        }
-        if (sc[3] < 1.0f) { // translucent first hit: direct-lit fallback (comp:548-553)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                float direct = a.global_light[k] * ndotl;
-                float lit = sc[k] * direct;
-                fc[k] = fc[k] + tc[k] * lit * 1.0f;
-            }
-        } else {
-            float emission = hv.p[1] * 10.0f;
-            if (emission > 0.0f) { // comp:575-578
-#pragma unroll
-                for (int k = 0; k < 3; ++k) fc[k] = fc[k] + tc[k] * sc[k] * emission * 1.0f;
-            } else {
-                int lit = 1;
-                if (MODE == 1) lit = not_in_shadow<USE_LDS>(a, lds, root, add3(h.point, scale3(normal, 2e-3f)), light);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    float direct = a.global_light[k] * (float)lit * ndotl;
-                    fc[k] = fc[k] + direct * sc[k] * tc[k] * 1.0f / kPI;
-                }
-            }
-        }
-    }
-    rgba = unorm8(fc[0]) | (unorm8(fc[1]) << 8) | (unorm8(fc[2]) << 16) | (255u << 24);
-    idd = make_int2(voxel_id, pixel_dist);
-}
-
-// One lane per pixel; a wave covers a TW x TH pixel tile (TW*TH == 64) so the
-// 64 rays of a wave stay spatially coherent; workgroups walk tiles with a
-// grid-stride loop so the LDS prefix is staged once per workgroup.
-template <int MODE, bool USE_LDS, int TW, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void trace_kernel(const KArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint2 lds_nodes[];
-    constexpr int TH = 64 / TW;
-    constexpr int WAVES = BLOCK / 64;
-    if (USE_LDS) {
-        for (uint32_t i = threadIdx.x; i < a.lds_records; i += BLOCK) lds_nodes[i] = a.nodes[i];
-        __syncthreads();
-    }
-    const uint2 root = a.nodes[0];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int tiles_x = (a.width + TW - 1) / TW;
-    const int tiles_y = (a.n_rows + TH - 1) / TH;
-    const int n_tiles = tiles_x * tiles_y;
-    const int lx = lane % TW, ly = lane / TW;
-    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
-        int tx = tile % tiles_x, ty = tile / tiles_x;
-        int px = tx * TW + lx;
-        int j = ty * TH + ly;
-        if (px < a.width && j < a.n_rows) {
-            int py = a.row0 + (j / a.tile_rows) * a.row_stride + (j % a.tile_rows);
-            uint32_t rgba;
-            int2 idd;
-            trace_pixel<MODE, USE_LDS>(a, lds_nodes, root, px, py, rgba, idd);
-            size_t o = (size_t)(a.compact ? j : py) * (size_t)a.width + (size_t)px;
-            if (a.out_rgba) a.out_rgba[o] = rgba;
-            if (a.out_id) a.out_id[o] = idd;
-        }
-    }
-}
-
-// exactness probe for the arithmetic contract: out[i] = op(x[i], y[i])
-__global__ void math_probe_kernel(int op, const float *x, const float *y, float *out, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float a = x[i], b = y[i], r = 0.0f;
-    switch (op) {
-        case 0: r = a / b; break;
-        case 1: r = __builtin_sqrtf(a); break;
-        case 2: r = 1.0f / __builtin_sqrtf(a); break;
-        case 3: r = __builtin_floorf(a); break;
-        case 4: r = __builtin_rintf(a); break;
-        case 5: r = a * b + 1.0f; break;          // must NOT be fused
-        case 6: r = det_expf(a); break;
-        case 7: r = (float)(int)a; break;
-        case 8: r = a + b; break;
-        case 9: r = a * b; break;
-        default: break;
-    }
-    out[i] = r;
-}
-
-} // namespace vrt
+}  // namespace v1
+}  // namespace vrt
