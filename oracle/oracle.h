@@ -122,6 +122,11 @@ void o_render(const o_scene *s, int width, int height, int row0, int row1, int m
 int o_find_point(const o_scene *s, const int32_t pos[3], uint8_t leaf[8],
                  int32_t mn[3], int32_t mx[3]);
 
+/* traversal-study hook: one record per in-world octreeFind (depth of the node found, depth the descent started at) */
+typedef struct { uint32_t pixel; int16_t x, y, z; uint8_t found_depth, start_depth, leaf, pad; } o_find_rec;
+void o_set_find_trace(o_find_rec *buf, size_t cap);
+size_t o_find_trace_count(void);
+
 uint64_t o_fnv1a64(const uint8_t *p, size_t n);
 
 /* deterministic fp32 transcendental conventions shared (by restatement) with the kernels */

@@ -58,7 +58,15 @@ typedef struct {
     o_stats st;
     uint32_t px_fetches;
     uint32_t rng;
+    uint32_t px_index;   /* y*W + x of the pixel being traced (find trace only) */
+    int par_depth;       /* depth of the cached parent (find trace only) */
 } ctx_t;
+
+/* optional find trace for traversal studies (tools/): one record per octreeFind call inside the world */
+static o_find_rec *g_trace = NULL;
+static size_t g_trace_cap = 0, g_trace_n = 0;
+void o_set_find_trace(o_find_rec *buf, size_t cap) { g_trace = buf; g_trace_cap = cap; g_trace_n = 0; }
+size_t o_find_trace_count(void) { return g_trace_n; }
 
 #define MAX_RAYS 8
 #define BOUNCES 1
@@ -198,6 +206,7 @@ static vox_t octree_find(ctx_t *c, i3 wp, i3 *min_b, i3 *max_b, int32_t *cur_coo
     }
     int inside = wp.x >= min_b->x && wp.y >= min_b->y && wp.z >= min_b->z &&
                  wp.x < max_b->x && wp.y < max_b->y && wp.z < max_b->z;
+    int depth = (inside && *cur_coord != 0) ? c->par_depth : 0, start_depth = depth; /* coord 0 = root */
     if (inside) { d.coord = *cur_coord; d.nmin = *min_b; d.nmax = *max_b; }
     else {
         c->st.root_restarts++;
@@ -209,6 +218,11 @@ static vox_t octree_find(ctx_t *c, i3 wp, i3 *min_b, i3 *max_b, int32_t *cur_coo
     for (int i = 0; i < 16; i++) {
         uint32_t nd = fetch(c, d.coord);
         if (is_leaf) {
+            if (g_trace && g_trace_n < g_trace_cap) {
+                o_find_rec *r = &g_trace[g_trace_n++];
+                r->pixel = c->px_index; r->x = (int16_t)wp.x; r->y = (int16_t)wp.y; r->z = (int16_t)wp.z;
+                r->found_depth = (uint8_t)depth; r->start_depth = (uint8_t)start_depth; r->leaf = 1;
+            }
             uint32_t pd = fetch(c, d.coord + 1);
             d.color[0] = (float)(nd & 0xff) / 255.0f;
             d.color[1] = (float)((nd >> 8) & 0xff) / 255.0f;
@@ -231,11 +245,21 @@ static vox_t octree_find(ctx_t *c, i3 wp, i3 *min_b, i3 *max_b, int32_t *cur_coo
         uint32_t next = ptr & 0x7fffffu;
         is_leaf = (ptr & 0x800000u) != 0;
         *cur_coord = d.coord; *min_b = d.nmin; *max_b = d.nmax;
+        c->par_depth = depth;
+        depth++;
         d.coord = (int32_t)next;
         if (ci & 4) d.nmin.x = mid.x; else d.nmax.x = mid.x;  /* comp:105-118 */
         if (ci & 2) d.nmin.y = mid.y; else d.nmax.y = mid.y;
         if (ci & 1) d.nmin.z = mid.z; else d.nmax.z = mid.z;
-        if (!exists) { d.color[0] = d.color[1] = d.color[2] = d.color[3] = 0.0f; return d; }
+        if (!exists) {
+            if (g_trace && g_trace_n < g_trace_cap) {
+                o_find_rec *r = &g_trace[g_trace_n++];
+                r->pixel = c->px_index; r->x = (int16_t)wp.x; r->y = (int16_t)wp.y; r->z = (int16_t)wp.z;
+                r->found_depth = (uint8_t)depth; r->start_depth = (uint8_t)start_depth; r->leaf = 0;
+            }
+            d.color[0] = d.color[1] = d.color[2] = d.color[3] = 0.0f;
+            return d;
+        }
     }
     return d;
 }
@@ -557,6 +581,7 @@ void o_render(const o_scene *s, int W, int H, int row0, int row1, int mode, uint
     for (int py = row0; py < row1; py++) {
         for (int px = 0; px < W; px++) {
             c.px_fetches = 0;
+            c.px_index = (uint32_t)(py * W + px);
             init_rng(&c, px, py, 0);
             float u = ((float)px / (float)W) * 2.0f - 1.0f;
             float v = ((float)py / (float)H) * 2.0f - 1.0f;

@@ -130,6 +130,44 @@ def test_degenerate_inputs(ctx, V, O, product_scenes):
     assert np.all(idd[..., 0] == 0) and np.all(idd[..., 1] == 2047)
 
 
+def _tx(value, alpha):
+    return [value & 255, (value >> 8) & 255, (value >> 16) & 255, alpha]
+
+
+def test_custom_world_bounds_and_unit_internal_node(ctx, V, O):
+    """Hand-written texel streams in a small world [0,8)^3 (u_worldBoundsMin/Max are uniforms):
+    (a) a regular tree, (b) a tree whose unit cell [4,5)^3 is still an internal node -- never written
+    by octree_texture(), outside the bit-indexed traversal's precondition, so the dispatcher must
+    route it to the explicit-AABB kernels and still match the shader arithmetic."""
+    leaf = [200, 40, 90, 255, 255, 0, 0, 255]
+    regular = _tx(1, 0x81) + _tx(3 | 0x800000, 0) + _tx(5, 0) + leaf + _tx(6, 0x01) + _tx(7 | 0x800000, 0) + leaf
+    unit = (_tx(1, 0x80) + _tx(2, 0) + _tx(3, 0x01) + _tx(4, 0) + _tx(5, 0x01) + _tx(6, 0) + _tx(7, 0x80) +
+            _tx(8 | 0x800000, 0) + leaf)
+    for name, stream in (("regular", regular), ("unit-internal", unit)):
+        tex = np.array(stream, np.uint8)
+        W, H = 64, 48
+        ip, iv, cp, _ = V.camera_block((1.3, 2.1, 0.7), 52.0, 18.0, W, H)
+        ctx.upload_octree(tex, 3)
+        ctx.set_camera(ip, iv, cp)
+        p = ctx.default_params()
+        p.world_min[:] = (0, 0, 0)
+        p.world_max[:] = (8, 8, 8)
+        ctx.set_params(p)
+        s = O.make_scene(tex, 3, ip, iv, cp)
+        s.bounds_min[:] = (0, 0, 0)
+        s.bounds_max[:] = (8, 8, 8)
+        for mode in (0, 1):
+            ref_rgba, ref_id, _, st = O.render(s, W, H, mode)
+            assert st["hits"] > 20, name
+            for v in (0, 1, 2):
+                ctx.set_variant(v)
+                rgba, idd = ctx.dispatch(W, H, mode)
+                _assert_same(rgba, ref_rgba, f"{name} mode {mode} variant {v} rgba8")
+                _assert_same(idd, ref_id, f"{name} mode {mode} variant {v} id/dist")
+    ctx.set_variant(0)
+    ctx.set_params(ctx.default_params())
+
+
 def test_materials_highlight_and_translucent_fallback(ctx, V, O):
     """Emissive, translucent and highlighted voxels + a camera sitting inside a translucent medium."""
     w = V.World()
@@ -177,6 +215,7 @@ def test_row_sharding_properties_at_full_size(ctx, V, golden, product_scenes):
     # contiguous row blocks written in place
     d_rgba = torch.zeros((H, W), dtype=torch.int32, device=dev)
     d_id = torch.zeros((H, W, 2), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()  # the fills run on torch's stream, the dispatch on the context's own
     for r0, r1 in [(0, 135), (135, 541), (541, 1079), (1079, 1080)]:
         ctx.dispatch_rows(W, H, r0, r1, 1, d_rgba.data_ptr(), d_id.data_ptr())
     ctx.synchronize()
@@ -193,6 +232,7 @@ def test_row_sharding_properties_at_full_size(ctx, V, golden, product_scenes):
                 continue
             sr = torch.zeros((len(rows), W), dtype=torch.int32, device=dev)
             si = torch.zeros((len(rows), W, 2), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()  # the fills run on torch's stream, the dispatch on the context's own
             ctx.dispatch_shard(W, H, tile_rows, s, n_shards, 1, sr.data_ptr(), si.data_ptr())
             ctx.synchronize()
             out_rgba[rows] = sr.cpu().numpy().view(np.uint8).reshape(len(rows), W, 4)

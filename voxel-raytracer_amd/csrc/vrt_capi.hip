@@ -64,6 +64,11 @@ struct vrt_ctx {
     bool profiling = false;
     std::vector<hipEvent_t> prof_events;  // 2 per slot
     size_t prof_count = 0;
+    // host copy of the records: lets the dispatcher check the bit-indexed traversal's precondition
+    // against the CURRENT world bounds (they arrive separately, through vrt_set_params)
+    std::vector<vrt::Record> host_records;
+    bool analysis_valid = false;
+    bool unit_internal = false;
     std::string err;
 };
 
@@ -129,7 +134,15 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
         return fail(c, VRT_E_INVALID, mode == VRT_MODE_FULL ? "VRT_MODE_FULL is not implemented by this build"
                                                              : "unknown mode");
     if (n_rows <= 0) return VRT_OK;
-    const Variant &v = kVariants[c->variant];
+    if (!c->analysis_valid) {
+        c->unit_internal = vrt::has_unit_internal_node(c->host_records, c->params.world_min, c->params.world_max);
+        c->analysis_valid = true;
+    }
+    Variant v = kVariants[c->variant];
+    if (v.trav == 2 && c->unit_internal) {  // precondition of vrt_kernels.hip.h not met: explicit-AABB kernels
+        v.trav = 1; v.tw = 8; v.block = 256;
+        if (v.lds_cap > 2048) v.lds_cap = 2048;
+    }
     vrt::KArgs a;
     std::memcpy(a.inv_proj, c->inv_proj, sizeof a.inv_proj);
     std::memcpy(a.inv_view, c->inv_view, sizeof a.inv_view);
@@ -256,6 +269,7 @@ int vrt_set_params(vrt_ctx *c, const vrt_params *p) {
     for (int i = 0; i < 3; ++i)
         if (p->world_max[i] < p->world_min[i]) return fail(c, VRT_E_INVALID, "vrt_set_params: world_max < world_min");
     c->params = *p;
+    c->analysis_valid = false;
     return VRT_OK;
 }
 
@@ -287,6 +301,8 @@ int vrt_upload_octree(vrt_ctx *c, const uint8_t *texels, size_t used_bytes, uint
     c->info.n_leaves = lay.n_leaves;
     c->info.max_depth = lay.max_depth;
     c->info.lds_records = 0;
+    c->host_records.swap(lay.records);
+    c->analysis_valid = false;
     c->have_scene = true;
     return VRT_OK;
 }

@@ -160,7 +160,10 @@ VRT_DEV void trace_pixel(const KArgs &a, const typename TRAV::Ctx &tc_, int px, 
     const float sky[3] = {0.5f, 0.7f, 1.0f};
 
     Hit h;
-    bool hit = TRAV::march(a, tc_, gro, ray_dir, start_iof, h);
+    // byte form of start_iof for traversals that test media on bytes: r(b) in (0, 3) <=> 1 <= b <= 254, else 1.0 == r(85)
+    const uint32_t eye_b = e1 & 0xffu;
+    const uint32_t iof_byte = (eye_b >= 1u && eye_b <= 254u) ? eye_b : 85u;
+    bool hit = TRAV::march(a, tc_, gro, ray_dir, start_iof, iof_byte, h);
     if (!hit) {
         // distanceInMedium is still 0 here, so the absorption branch (comp:482) cannot fire
 #pragma unroll

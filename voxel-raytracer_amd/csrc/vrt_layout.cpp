@@ -73,4 +73,38 @@ bool build_layout(const uint8_t *texels, size_t used_bytes, Layout &out, std::st
     return true;
 }
 
+bool has_unit_internal_node(const std::vector<Record> &records, const int wmin[3], const int wmax[3]) {
+    struct Item { uint32_t rec; int mn[3], mx[3]; };
+    if (records.empty()) return false;
+    std::vector<Item> stack;
+    Item root;
+    root.rec = 0;
+    for (int k = 0; k < 3; ++k) { root.mn[k] = wmin[k]; root.mx[k] = wmax[k]; }
+    stack.push_back(root);
+    while (!stack.empty()) {
+        const Item it = stack.back();
+        stack.pop_back();
+        const uint32_t masks = records[it.rec].w0, base = records[it.rec].w1;
+        if ((masks & 0xffu) == 0) continue;  // no children: never descended through
+        if (it.mx[0] - it.mn[0] <= 1 && it.mx[1] - it.mn[1] <= 1 && it.mx[2] - it.mn[2] <= 1) return true;
+        uint32_t rank = 0;
+        for (uint32_t ci = 0; ci < 8; ++ci) {
+            if (!((masks >> ci) & 1u)) continue;
+            const uint32_t idx = base + rank++;
+            if ((masks >> (8 + ci)) & 1u) continue;  // leaf child
+            if (idx >= records.size()) continue;
+            Item ch;
+            ch.rec = idx;
+            for (int k = 0; k < 3; ++k) {
+                const int mid = it.mn[k] + ((it.mx[k] - it.mn[k]) >> 1);
+                const bool hi = (ci >> (2 - k)) & 1u;
+                ch.mn[k] = hi ? mid : it.mn[k];
+                ch.mx[k] = hi ? it.mx[k] : mid;
+            }
+            stack.push_back(ch);
+        }
+    }
+    return false;
+}
+
 }  // namespace vrt

@@ -37,4 +37,10 @@ struct Layout {
 // An empty stream yields a single root record with no children.
 bool build_layout(const uint8_t *texels, size_t used_bytes, Layout &out, std::string &err);
 
+// True when some INTERNAL node's AABB (under the world bounds given, split as the shader splits:
+// mid = min + (max - min) / 2) is no larger than one voxel in every axis. octree_texture() never
+// writes such a node; the bit-indexed traversal (vrt_kernels.hip.h) does not support it and the
+// dispatcher then falls back to the explicit-AABB kernels.
+bool has_unit_internal_node(const std::vector<Record> &records, const int wmin[3], const int wmax[3]);
+
 }  // namespace vrt
