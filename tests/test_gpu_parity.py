@@ -10,7 +10,7 @@ from conftest import MAPS
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = list(range(10))
+VARIANTS = list(range(19))
 
 
 @pytest.fixture(scope="module")
@@ -159,7 +159,7 @@ def test_custom_world_bounds_and_unit_internal_node(ctx, V, O):
         for mode in (0, 1):
             ref_rgba, ref_id, _, st = O.render(s, W, H, mode)
             assert st["hits"] > 20, name
-            for v in (0, 1, 2):
+            for v in (0, 1, 2, 13, 15):
                 ctx.set_variant(v)
                 rgba, idd = ctx.dispatch(W, H, mode)
                 _assert_same(rgba, ref_rgba, f"{name} mode {mode} variant {v} rgba8")

@@ -12,6 +12,7 @@
 
 #include "vrt_kernels.hip.h"
 #include "vrt_kernels_v1.hip.h"
+#include "vrt_kernels_wide.hip.h"
 #include "vrt_layout.h"
 
 namespace {
@@ -25,20 +26,31 @@ struct Variant {
     int block;         // threads per workgroup
     uint32_t lds_cap;  // max records staged in LDS
     int blocks_per_cu; // > 0: persistent grid of CUs*blocks_per_cu workgroups; 0: one pass over all tiles
+    int wpe;           // waves per SIMD the register allocator is held to (1 = unconstrained)
 };
 
 // variant 0 is the default the library ships with; the others exist for A/B measurement
+// (see launch_mode() for the combinations that are instantiated)
 const Variant kVariants[] = {
-    /*0*/ {2, false, 8, 256, 0, 0},
-    /*1*/ {1, false, 8, 256, 0, 0},
-    /*2*/ {2, true, 8, 256, 2048, 0},
-    /*3*/ {2, false, 16, 256, 0, 0},
-    /*4*/ {2, false, 8, 512, 0, 0},
-    /*5*/ {2, true, 8, 1024, 8192, 0},
-    /*6*/ {2, false, 8, 256, 0, 8},
-    /*7*/ {1, true, 8, 256, 2048, 0},
-    /*8*/ {2, false, 64, 256, 0, 0},
-    /*9*/ {2, false, 8, 1024, 0, 0},
+    /*0*/ {2, false, 8, 256, 0, 0, 1},
+    /*1*/ {1, false, 8, 256, 0, 0, 1},
+    /*2*/ {2, true, 8, 256, 2048, 0, 1},
+    /*3*/ {2, false, 16, 256, 0, 0, 1},
+    /*4*/ {2, false, 8, 512, 0, 0, 1},
+    /*5*/ {2, true, 8, 1024, 8192, 0, 1},
+    /*6*/ {2, false, 8, 256, 0, 8, 1},
+    /*7*/ {1, true, 8, 256, 2048, 0, 1},
+    /*8*/ {2, false, 8, 64, 0, 0, 1},
+    /*9*/ {2, false, 8, 128, 0, 0, 1},
+    /*10*/ {2, false, 8, 256, 0, 0, 5},
+    /*11*/ {2, false, 8, 256, 0, 0, 6},
+    /*12*/ {2, false, 8, 256, 0, 0, 8},
+    /*13*/ {3, false, 8, 256, 0, 0, 1},
+    /*14*/ {3, false, 8, 256, 0, 0, 6},
+    /*15*/ {3, false, 8, 256, 0, 0, 8},
+    /*16*/ {3, false, 8, 64, 0, 0, 1},
+    /*17*/ {3, false, 8, 64, 0, 0, 8},
+    /*18*/ {3, false, 16, 256, 0, 0, 1},
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -69,6 +81,11 @@ struct vrt_ctx {
     std::vector<vrt::Record> host_records;
     bool analysis_valid = false;
     bool unit_internal = false;
+    // wide layout (vrt_layout.h), rebuilt whenever the tree or the world bounds change
+    bool wide_ok = false;
+    vrt::WideTree wide;
+    uint2 *d_cells = nullptr;
+    size_t cells_capacity = 0;
     std::string err;
 };
 
@@ -86,43 +103,51 @@ int fail(vrt_ctx *c, int code, const std::string &msg) {
             return fail((c), VRT_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-template <int MODE, class TRAV, int TW, int BLOCK>
+template <int MODE, class TRAV, int TW, int BLOCK, int WPE>
 hipError_t launch_one(const vrt::KArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
     if (lds_bytes > 48 * 1024) {  // above the default dynamic-LDS ceiling: opt in (CDNA4 has 160 KiB per CU)
         static bool raised = false;
         if (!raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&vrt::trace_kernel<MODE, TRAV, TW, BLOCK>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             if (e != hipSuccess) return e;
             raised = true;
         }
     }
-    hipLaunchKernelGGL((vrt::trace_kernel<MODE, TRAV, TW, BLOCK>), dim3(grid), dim3(BLOCK), lds_bytes, s, a);
+    hipLaunchKernelGGL((vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE>), dim3(grid), dim3(BLOCK), lds_bytes, s, a);
     return hipGetLastError();
 }
 
-template <int MODE, class TRAV>
-hipError_t launch_shape(int tw, int block, const vrt::KArgs &a, int grid, size_t lds, hipStream_t s) {
-    const int key = tw * 10000 + block;
-    switch (key) {
-        case 8 * 10000 + 256: return launch_one<MODE, TRAV, 8, 256>(a, grid, lds, s);
-        case 8 * 10000 + 512: return launch_one<MODE, TRAV, 8, 512>(a, grid, lds, s);
-        case 8 * 10000 + 1024: return launch_one<MODE, TRAV, 8, 1024>(a, grid, lds, s);
-        case 16 * 10000 + 256: return launch_one<MODE, TRAV, 16, 256>(a, grid, lds, s);
-        case 64 * 10000 + 256: return launch_one<MODE, TRAV, 64, 256>(a, grid, lds, s);
-        default: return hipErrorInvalidValue;
-    }
-}
-
+// The instantiated (traversal, LDS prefix, tile width, workgroup size, waves-per-SIMD) combinations.
 template <int MODE>
 hipError_t launch_mode(const Variant &v, const vrt::KArgs &a, int grid, size_t lds, hipStream_t s) {
-    if (v.trav == 1) {  // baseline traversal: one shape only
-        if (v.tw != 8 || v.block != 256) return hipErrorInvalidValue;
-        return v.use_lds ? launch_one<MODE, vrt::v1::Trav<true>, 8, 256>(a, grid, lds, s)
-                         : launch_one<MODE, vrt::v1::Trav<false>, 8, 256>(a, grid, lds, s);
+    using V1 = vrt::v1::Trav<false>;
+    using V1L = vrt::v1::Trav<true>;
+    using V2 = vrt::v2::Trav<false>;
+    using V2L = vrt::v2::Trav<true>;
+    using V3 = vrt::v3::Trav;
+    const int key = v.trav * 1000000 + (v.use_lds ? 100000 : 0) + v.tw * 1000 + (v.block / 64) * 10 + v.wpe;
+    switch (key) {
+        case 1000000 + 8000 + 40 + 1: return launch_one<MODE, V1, 8, 256, 1>(a, grid, lds, s);
+        case 1100000 + 8000 + 40 + 1: return launch_one<MODE, V1L, 8, 256, 1>(a, grid, lds, s);
+        case 2000000 + 8000 + 40 + 1: return launch_one<MODE, V2, 8, 256, 1>(a, grid, lds, s);
+        case 2000000 + 8000 + 40 + 5: return launch_one<MODE, V2, 8, 256, 5>(a, grid, lds, s);
+        case 2000000 + 8000 + 40 + 6: return launch_one<MODE, V2, 8, 256, 6>(a, grid, lds, s);
+        case 2000000 + 8000 + 40 + 8: return launch_one<MODE, V2, 8, 256, 8>(a, grid, lds, s);
+        case 2000000 + 16000 + 40 + 1: return launch_one<MODE, V2, 16, 256, 1>(a, grid, lds, s);
+        case 2000000 + 8000 + 80 + 1: return launch_one<MODE, V2, 8, 512, 1>(a, grid, lds, s);
+        case 2000000 + 8000 + 10 + 1: return launch_one<MODE, V2, 8, 64, 1>(a, grid, lds, s);
+        case 2000000 + 8000 + 20 + 1: return launch_one<MODE, V2, 8, 128, 1>(a, grid, lds, s);
+        case 2100000 + 8000 + 40 + 1: return launch_one<MODE, V2L, 8, 256, 1>(a, grid, lds, s);
+        case 2100000 + 8000 + 160 + 1: return launch_one<MODE, V2L, 8, 1024, 1>(a, grid, lds, s);
+        case 3000000 + 8000 + 40 + 1: return launch_one<MODE, V3, 8, 256, 1>(a, grid, lds, s);
+        case 3000000 + 8000 + 40 + 6: return launch_one<MODE, V3, 8, 256, 6>(a, grid, lds, s);
+        case 3000000 + 8000 + 40 + 8: return launch_one<MODE, V3, 8, 256, 8>(a, grid, lds, s);
+        case 3000000 + 8000 + 10 + 1: return launch_one<MODE, V3, 8, 64, 1>(a, grid, lds, s);
+        case 3000000 + 8000 + 10 + 8: return launch_one<MODE, V3, 8, 64, 8>(a, grid, lds, s);
+        case 3000000 + 16000 + 40 + 1: return launch_one<MODE, V3, 16, 256, 1>(a, grid, lds, s);
+        default: return hipErrorInvalidValue;
     }
-    return v.use_lds ? launch_shape<MODE, vrt::v2::Trav<true>>(v.tw, v.block, a, grid, lds, s)
-                     : launch_shape<MODE, vrt::v2::Trav<false>>(v.tw, v.block, a, grid, lds, s);
 }
 
 // Builds the kernel arguments for local rows [0, n_rows) and enqueues one launch.
@@ -135,12 +160,34 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
                                                              : "unknown mode");
     if (n_rows <= 0) return VRT_OK;
     if (!c->analysis_valid) {
+        // the world bounds decide which sub-trees are aligned cubes: (re)derive the layouts that depend on them
         c->unit_internal = vrt::has_unit_internal_node(c->host_records, c->params.world_min, c->params.world_max);
+        std::string why;
+        c->wide_ok = !c->unit_internal &&
+                     vrt::build_wide(c->host_records, c->params.world_min, c->params.world_max, c->wide, why);
+        if (c->wide_ok) {
+            const size_t bytes = (c->wide.cells.empty() ? 64 : c->wide.cells.size()) * sizeof(vrt::WideCell);
+            if (bytes > c->cells_capacity) {
+                VRT_HIP(c, hipDeviceSynchronize());
+                if (c->d_cells) VRT_HIP(c, hipFree(c->d_cells));
+                c->d_cells = nullptr;
+                c->cells_capacity = 0;
+                VRT_HIP(c, hipMalloc((void **)&c->d_cells, bytes));
+                c->cells_capacity = bytes;
+            }
+            // rare (scene or bounds changed): a blocking copy keeps it ordered against any caller stream
+            VRT_HIP(c, hipDeviceSynchronize());
+            if (!c->wide.cells.empty())
+                VRT_HIP(c, hipMemcpy(c->d_cells, c->wide.cells.data(), c->wide.cells.size() * sizeof(vrt::WideCell), hipMemcpyHostToDevice));
+        }
         c->analysis_valid = true;
     }
     Variant v = kVariants[c->variant];
+    if (v.trav == 3 && !c->wide_ok) {  // wide layout not expressible for this scene: record-array kernels
+        v.trav = 2; v.use_lds = false; v.tw = 8; v.block = 256; v.wpe = 1; v.lds_cap = 0;
+    }
     if (v.trav == 2 && c->unit_internal) {  // precondition of vrt_kernels.hip.h not met: explicit-AABB kernels
-        v.trav = 1; v.tw = 8; v.block = 256;
+        v.trav = 1; v.tw = 8; v.block = 256; v.wpe = 1;
         if (v.lds_cap > 2048) v.lds_cap = 2048;
     }
     vrt::KArgs a;
@@ -168,6 +215,14 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     a.lds_records = v.use_lds ? (c->info.n_records < v.lds_cap ? c->info.n_records : v.lds_cap) : 0u;
     a.out_rgba = (uint32_t *)d_rgba;
     a.out_id = (int2 *)d_id;
+    a.cells = c->d_cells;
+    a.n_roots = c->wide_ok ? (uint32_t)c->wide.roots.size() : 0u;
+    for (int i = 0; i < 8; ++i) {
+        const bool on = (uint32_t)i < a.n_roots;
+        a.root_record[i] = on ? c->wide.roots[(size_t)i].record : 0xffffffffu;
+        a.root_node[i] = on ? c->wide.roots[(size_t)i].node : 0u;
+        a.root_shift[i] = on ? c->wide.roots[(size_t)i].shift : 0;
+    }
 
     const int th = 64 / v.tw;
     const long tiles = (long)((width + v.tw - 1) / v.tw) * (long)((n_rows + th - 1) / th);
@@ -255,6 +310,7 @@ void vrt_destroy(vrt_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_nodes) (void)hipFree(c->d_nodes);
+    if (c->d_cells) (void)hipFree(c->d_cells);
     if (c->d_rgba) (void)hipFree(c->d_rgba);
     if (c->d_id) (void)hipFree(c->d_id);
     for (auto &e : c->prof_events) (void)hipEventDestroy(e);
@@ -462,6 +518,28 @@ int vrt_debug_math(vrt_ctx *c, int op, const float *x, const float *y, float *ou
     VRT_HIP(c, hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, c->stream));
     VRT_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
+    return VRT_OK;
+}
+
+// Host-only check of the wide layout (tests without a GPU): builds it for the texel stream and world
+// bounds and answers n point queries through it. out: n * 8 words = w0, w1, mn[3], mx[3].
+// stats (optional): wide nodes, roots. Returns 0, VRT_E_MALFORMED, or VRT_E_STATE when the scene has no wide form.
+int vrt_debug_wide_find(const uint8_t *texels, size_t used_bytes, const int32_t wmin[3], const int32_t wmax[3],
+                        const int32_t *points, size_t n, uint32_t *out, uint32_t *stats) {
+    vrt::Layout lay;
+    std::string err;
+    if (!vrt::build_layout(texels, used_bytes, lay, err)) return VRT_E_MALFORMED;
+    vrt::WideTree wt;
+    if (!vrt::build_wide(lay.records, wmin, wmax, wt, err)) return VRT_E_STATE;
+    if (stats) { stats[0] = wt.n_nodes; stats[1] = (uint32_t)wt.roots.size(); }
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t w0, w1;
+        int mn[3], mx[3];
+        (void)vrt::wide_find_host(lay.records, wt, wmin, wmax, points + 3 * i, w0, w1, mn, mx);
+        uint32_t *o = out + 8 * i;
+        o[0] = w0; o[1] = w1;
+        for (int k = 0; k < 3; ++k) { o[2 + k] = (uint32_t)mn[k]; o[5 + k] = (uint32_t)mx[k]; }
+    }
     return VRT_OK;
 }
 

@@ -42,6 +42,12 @@ struct KArgs {
     uint32_t lds_records;     // prefix of `nodes` staged in LDS by each workgroup
     uint32_t *out_rgba;       // packed R | G<<8 | B<<16 | A<<24
     int2 *out_id;             // (voxelID, dist)
+    // wide layout (vrt_layout.h): 64 cells per node; roots = octree records where a wide tree starts
+    const uint2 *cells;
+    uint32_t n_roots;
+    uint32_t root_record[8];
+    uint32_t root_node[8];
+    int root_shift[8];
 };
 
 #define VRT_DEV __device__ __forceinline__
@@ -229,8 +235,9 @@ VRT_DEV void trace_pixel(const KArgs &a, const typename TRAV::Ctx &tc_, int px, 
 
 // One lane per pixel; a wave covers a TW x TH pixel tile (TW*TH == 64) so the 64 rays of a wave
 // stay spatially coherent; workgroups walk tiles with a grid-stride loop.
-template <int MODE, class TRAV, int TW, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void trace_kernel(const KArgs a) {
+// WPE: waves per SIMD the register allocator must leave room for (1 = no constraint beyond BLOCK).
+template <int MODE, class TRAV, int TW, int BLOCK, int WPE = 1>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) void trace_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint2 lds_dyn[];
     constexpr int TH = 64 / TW;
     constexpr int WAVES = BLOCK / 64;

@@ -73,6 +73,159 @@ bool build_layout(const uint8_t *texels, size_t used_bytes, Layout &out, std::st
     return true;
 }
 
+namespace {
+
+struct Box { int mn[3], mx[3]; };
+
+// aligned cube of even log2 side >= 2 (the shape a wide node covers)
+bool aligned_even_cube(const Box &b, int &shift) {
+    const int sx = b.mx[0] - b.mn[0];
+    if (sx != b.mx[1] - b.mn[1] || sx != b.mx[2] - b.mn[2]) return false;
+    if (sx < 4 || sx > (1 << 30) || (sx & (sx - 1)) != 0) return false;
+    if (((b.mn[0] | b.mn[1] | b.mn[2]) & (sx - 1)) != 0) return false;
+    int s = 0;
+    while ((1 << s) < sx) ++s;
+    if (s & 1) return false;
+    shift = s;
+    return true;
+}
+
+Box child_box(const Box &b, uint32_t ci) {  // the shader's split: mid = min + (max - min) / 2
+    Box c;
+    for (int k = 0; k < 3; ++k) {
+        const int mid = b.mn[k] + ((b.mx[k] - b.mn[k]) >> 1);
+        const bool hi = (ci >> (2 - k)) & 1u;
+        c.mn[k] = hi ? mid : b.mn[k];
+        c.mx[k] = hi ? b.mx[k] : mid;
+    }
+    return c;
+}
+
+enum { kAbsent = 0, kLeaf = 1, kInternal = 2 };
+int child_of(const std::vector<Record> &recs, uint32_t rec, uint32_t ci, uint32_t &idx) {
+    const uint32_t masks = recs[rec].w0, bit = 1u << ci;
+    if (!(masks & bit)) return kAbsent;
+    idx = recs[rec].w1 + (uint32_t)__builtin_popcount(masks & 0xffu & (bit - 1u));
+    if (idx >= recs.size()) return kAbsent;  // cannot happen for layouts build_layout() produced
+    return (masks & (bit << 8)) ? kLeaf : kInternal;
+}
+
+bool build_wide_node(const std::vector<Record> &recs, uint32_t rec, int shift, WideTree &out, uint32_t &node, std::string &why) {
+    node = out.n_nodes++;
+    out.cells.resize((size_t)out.n_nodes * 64, WideCell{0u, 0u});
+    for (uint32_t cell = 0; cell < 64; ++cell) {
+        const uint32_t cx = (cell >> 4) & 3u, cy = (cell >> 2) & 3u, cz = cell & 3u;
+        const uint32_t hi = ((cx >> 1) << 2) | ((cy >> 1) << 1) | (cz >> 1);
+        const uint32_t lo = ((cx & 1u) << 2) | ((cy & 1u) << 1) | (cz & 1u);
+        uint32_t i1 = 0, i2 = 0;
+        WideCell c{0u, 0u};
+        const int k1 = child_of(recs, rec, hi, i1);
+        if (k1 == kAbsent) {
+            c.w1 = (uint32_t)(shift - 1) << 24;
+        } else if (k1 == kLeaf) {
+            c.w0 = recs[i1].w0;
+            c.w1 = (recs[i1].w1 & 0x00ffffffu) | ((uint32_t)(shift - 1) << 24);
+        } else {
+            const int k2 = child_of(recs, i1, lo, i2);
+            if (k2 == kAbsent) {
+                c.w1 = (uint32_t)(shift - 2) << 24;
+            } else if (k2 == kLeaf) {
+                c.w0 = recs[i2].w0;
+                c.w1 = (recs[i2].w1 & 0x00ffffffu) | ((uint32_t)(shift - 2) << 24);
+            } else {
+                if (shift - 2 < 2) {
+                    why = "an internal node of unit size lies inside an aligned cube";
+                    return false;
+                }
+                uint32_t child = 0;
+                if (!build_wide_node(recs, i2, shift - 2, out, child, why)) return false;
+                c.w0 = child;
+                c.w1 = kWideInternal;
+            }
+        }
+        out.cells[(size_t)node * 64 + cell] = c;
+    }
+    return true;
+}
+
+bool collect_roots(const std::vector<Record> &recs, uint32_t rec, const Box &box, int depth, WideTree &out, std::string &why) {
+    if ((recs[rec].w0 & 0xffu) == 0 || depth > 16) return true;
+    int shift = 0;
+    if (aligned_even_cube(box, shift)) {
+        if ((int)out.roots.size() >= kMaxWideRoots) {
+            why = "more aligned sub-trees than the kernel's root table holds";
+            return false;
+        }
+        uint32_t node = 0;
+        if (!build_wide_node(recs, rec, shift, out, node, why)) return false;
+        out.roots.push_back(WideRoot{rec, node, shift});
+        return true;
+    }
+    for (uint32_t ci = 0; ci < 8; ++ci) {
+        uint32_t idx = 0;
+        if (child_of(recs, rec, ci, idx) == kInternal)
+            if (!collect_roots(recs, idx, child_box(box, ci), depth + 1, out, why)) return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+bool build_wide(const std::vector<Record> &records, const int wmin[3], const int wmax[3], WideTree &out, std::string &why) {
+    out = WideTree();
+    if (records.empty()) return true;
+    if (has_unit_internal_node(records, wmin, wmax)) {
+        why = "an internal node of unit size";
+        return false;
+    }
+    Box world;
+    for (int k = 0; k < 3; ++k) { world.mn[k] = wmin[k]; world.mx[k] = wmax[k]; }
+    return collect_roots(records, 0, world, 0, out, why);
+}
+
+int wide_find_host(const std::vector<Record> &records, const WideTree &wt, const int wmin[3], const int wmax[3],
+                   const int p[3], uint32_t &w0, uint32_t &w1, int mn[3], int mx[3]) {
+    Box b;
+    for (int k = 0; k < 3; ++k) { b.mn[k] = wmin[k]; b.mx[k] = wmax[k]; }
+    w0 = w1 = 0;
+    uint32_t rec = 0;
+    for (int i = 0; i < 16; ++i) {
+        int shift = 0;
+        const WideRoot *root = nullptr;
+        if ((records[rec].w0 & 0xffu) != 0 && aligned_even_cube(b, shift))
+            for (const WideRoot &r : wt.roots)
+                if (r.record == rec) root = &r;
+        if (root) {
+            uint32_t node = root->node;
+            int s = root->shift;
+            for (;;) {
+                const int cs = s - 2;
+                const uint32_t ci = ((((uint32_t)p[0] >> cs) & 3u) << 4) | ((((uint32_t)p[1] >> cs) & 3u) << 2) | (((uint32_t)p[2] >> cs) & 3u);
+                const WideCell c = wt.cells[(size_t)node * 64 + ci];
+                if (c.w1 & kWideInternal) { node = c.w0; s = cs; continue; }
+                const int t = (int)((c.w1 >> 24) & 31u);
+                for (int k = 0; k < 3; ++k) { mn[k] = p[k] & -(1 << t); mx[k] = mn[k] + (1 << t); }
+                w0 = c.w0; w1 = c.w1 & 0x00ffffffu;
+                // a leaf whose alpha and words are all zero is indistinguishable from empty space for every consumer
+                return (c.w0 | w1) != 0 ? 1 : 0;
+            }
+        }
+        uint32_t ci = 0;
+        for (int k = 0; k < 3; ++k) {
+            const int mid = b.mn[k] + ((b.mx[k] - b.mn[k]) >> 1);
+            if (p[k] >= mid) ci |= 1u << (2 - k);
+        }
+        b = child_box(b, ci);
+        for (int k = 0; k < 3; ++k) { mn[k] = b.mn[k]; mx[k] = b.mx[k]; }
+        uint32_t idx = 0;
+        const int kind = child_of(records, rec, ci, idx);
+        if (kind == kAbsent) return 0;
+        if (kind == kLeaf) { w0 = records[idx].w0; w1 = records[idx].w1; return 1; }
+        rec = idx;
+    }
+    return 0;
+}
+
 bool has_unit_internal_node(const std::vector<Record> &records, const int wmin[3], const int wmax[3]) {
     struct Item { uint32_t rec; int mn[3], mx[3]; };
     if (records.empty()) return false;

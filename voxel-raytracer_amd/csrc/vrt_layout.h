@@ -43,4 +43,40 @@ bool build_layout(const uint8_t *texels, size_t used_bytes, Layout &out, std::st
 // dispatcher then falls back to the explicit-AABB kernels.
 bool has_unit_internal_node(const std::vector<Record> &records, const int wmin[3], const int wmax[3]);
 
+// ---------------------------------------------------------------------------------------------
+// Wide layout ("64-trees"), built from the record array once the world bounds are known.
+//
+// Inside an octree node whose AABB is an aligned cube of side 2^S (S even, >= 2) two octree levels
+// are collapsed into one DENSE node of 4x4x4 = 64 cells of side 2^(S-2), indexed directly by two
+// bits of each coordinate (cell = x2 << 4 | y2 << 2 | z2) -- no mask, no popcount, one 8-byte load
+// per TWO octree levels. A cell holds everything octreeFind would return for any point in it:
+//
+//   cell.w0, cell.w1[23:0] : the leaf words (0/0 = empty space)
+//   cell.w1[28:24]         : t = log2(side) of the octree node the point falls in (leaf or absent
+//                            child; it may be larger than the cell, then the cell is one of several
+//                            copies), from which the kernel rebuilds that node's AABB
+//   cell.w1[31] = 1        : the cell is subdivided further: w0 = index of the child wide node
+//
+// Wide trees are rooted at the octree nodes first met on the way down from the root that are
+// aligned cubes of even log2 side ("roots"); the few levels above them (the reference's world
+// [-1023,1024)^3 is not a power of two) stay in the record array and are walked with explicit AABBs.
+struct WideCell { uint32_t w0, w1; };
+struct WideRoot { uint32_t record; uint32_t node; int shift; };
+struct WideTree {
+    std::vector<WideCell> cells;   // 64 per wide node
+    std::vector<WideRoot> roots;
+    uint32_t n_nodes = 0;
+};
+constexpr uint32_t kWideInternal = 0x80000000u;
+constexpr int kMaxWideRoots = 8;
+
+// Returns false when the scene cannot be expressed (an internal node of unit size inside an aligned
+// cube, or more than kMaxWideRoots roots): the dispatcher then uses the record-array kernels.
+bool build_wide(const std::vector<Record> &records, const int wmin[3], const int wmax[3], WideTree &out, std::string &why);
+
+// Host mirror of the device lookup (tests): the octreeFind result for point p through the wide layout.
+// Returns 1 and the leaf words for a leaf, 0 for empty space; mn/mx receive the node AABB.
+int wide_find_host(const std::vector<Record> &records, const WideTree &wt, const int wmin[3], const int wmax[3],
+                   const int p[3], uint32_t &w0, uint32_t &w1, int mn[3], int mx[3]);
+
 }  // namespace vrt
