@@ -32,11 +32,11 @@ struct Variant {
 // variant 0 is the default the library ships with; the others exist for A/B measurement
 // (see launch_mode() for the combinations that are instantiated)
 const Variant kVariants[] = {
-    /*0*/ {2, false, 8, 256, 0, 0, 1},
+    /*0*/ {3, false, 8, 256, 0, 0, 6},
     /*1*/ {1, false, 8, 256, 0, 0, 1},
     /*2*/ {2, true, 8, 256, 2048, 0, 1},
     /*3*/ {2, false, 16, 256, 0, 0, 1},
-    /*4*/ {2, false, 8, 512, 0, 0, 1},
+    /*4*/ {2, false, 8, 256, 0, 0, 1},
     /*5*/ {2, true, 8, 1024, 8192, 0, 1},
     /*6*/ {2, false, 8, 256, 0, 8, 1},
     /*7*/ {1, true, 8, 256, 2048, 0, 1},

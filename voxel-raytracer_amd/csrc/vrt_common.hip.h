@@ -76,7 +76,8 @@ VRT_DEV float refraction_of(uint32_t w1) { return ((float)(w1 & 0xffu) / 255.0f)
 struct Hit {
     I3 map;           // hitMapPos
     F3 point;         // hitPoint
-    F3 normal;        // hitNormal
+    int axis;         // hitNormal = n on this axis, 0 elsewhere (comp:292-294)
+    float n;          // -sign(rayDir[axis]): +1, -1, or -0 for a zero direction component
     uint32_t p0, p1;  // prevVoxel leaf words
     uint32_t h0, h1;  // hitVoxel leaf words
 };
@@ -101,12 +102,10 @@ VRT_DEV float det_expf(float x) {
     return p * __uint_as_float((uint32_t)(ki + 127) << 23);
 }
 
-VRT_DEV int face_index(F3 n) {  // comp:419-433
-    if (len3(n) < 0.5f) return 0;
-    float ax = __builtin_fabsf(n.x), ay = __builtin_fabsf(n.y), az = __builtin_fabsf(n.z);
-    if (ax > ay && ax > az) return n.x > 0.0f ? 0 : 1;
-    else if (ay > az) return n.y > 0.0f ? 2 : 3;
-    else return n.z > 0.0f ? 4 : 5;
+// getFaceIndex (comp:419-433) of an axis normal: length(normal) is |n| (1 or 0), the dominant axis is `axis`
+VRT_DEV int face_index(int axis, float n) {
+    if (!(__builtin_fabsf(n) >= 0.5f)) return 0;
+    return axis * 2 + (n > 0.0f ? 0 : 1);
 }
 
 VRT_DEV uint32_t unorm8(float v) {  // rgba8 imageStore: clamp, scale, round to nearest even
@@ -119,23 +118,25 @@ VRT_DEV void mat_vec(const float *m, float x, float y, float z, float w, float o
     for (int r = 0; r < 4; ++r) out[r] = (m[0 * 4 + r] * x + m[1 * 4 + r] * y) + (m[2 * 4 + r] * z + m[3 * 4 + r] * w);
 }
 
+// Leaf words -> the shader's VoxelData floats (comp:173-178). `unorm` is the workgroup's 256-entry
+// table of (float)b / 255.0f, built with that very division, so a lookup returns the same bits.
 struct Decoded { float c[4]; float p[3]; };
-VRT_DEV Decoded decode_leaf(uint32_t w0, uint32_t w1) {  // comp:173-178
+VRT_DEV Decoded decode_leaf(const float *unorm, uint32_t w0, uint32_t w1) {
     Decoded d;
-    d.c[0] = (float)(w0 & 0xffu) / 255.0f;
-    d.c[1] = (float)((w0 >> 8) & 0xffu) / 255.0f;
-    d.c[2] = (float)((w0 >> 16) & 0xffu) / 255.0f;
-    d.c[3] = (float)(w0 >> 24) / 255.0f;
-    d.p[0] = ((float)(w1 & 0xffu) / 255.0f) * 3.0f;
-    d.p[1] = (float)((w1 >> 8) & 0xffu) / 255.0f;
-    d.p[2] = (float)((w1 >> 16) & 0xffu) / 255.0f;
+    d.c[0] = unorm[w0 & 0xffu];
+    d.c[1] = unorm[(w0 >> 8) & 0xffu];
+    d.c[2] = unorm[(w0 >> 16) & 0xffu];
+    d.c[3] = unorm[w0 >> 24];
+    d.p[0] = unorm[w1 & 0xffu] * 3.0f;
+    d.p[1] = unorm[(w1 >> 8) & 0xffu];
+    d.p[2] = unorm[(w1 >> 16) & 0xffu];
     return d;
 }
 
 // One pixel: ray generation (comp:624-641), primary-ray pathTrace, packing of the two outputs.
 // TRAV supplies the traversal: eye_medium(), march(), shadow(). MODE: 0 primary, 1 primary + shadow ray.
 template <int MODE, class TRAV>
-VRT_DEV void trace_pixel(const KArgs &a, const typename TRAV::Ctx &tc_, int px, int py, uint32_t &rgba, int2 &idd) {
+VRT_DEV void trace_pixel(const KArgs &a, const typename TRAV::Ctx &tc_, const float *unorm, int px, int py, uint32_t &rgba, int2 &idd) {
     const float kPI = 3.14159265359f;
     float u = ((float)px / (float)a.width) * 2.0f - 1.0f;
     float v = ((float)py / (float)a.height) * 2.0f - 1.0f;
@@ -154,7 +155,7 @@ VRT_DEV void trace_pixel(const KArgs &a, const typename TRAV::Ctx &tc_, int px, 
     // medium at the eye (comp:445-449)
     uint32_t e0, e1;
     TRAV::eye_medium(a, tc_, floor_i3(gro), e0, e1);
-    Decoded tvd = decode_leaf(e0, e1);
+    Decoded tvd = decode_leaf(unorm, e0, e1);
     float start_iof = (tvd.p[0] > 0.0f && tvd.p[0] < 3.0f) ? tvd.p[0] : 1.0f;
     float inv_len = 1.0f / __builtin_sqrtf(dot3(ray_dir, ray_dir));
     ray_dir = scale3(ray_dir, inv_len);
@@ -175,12 +176,18 @@ VRT_DEV void trace_pixel(const KArgs &a, const typename TRAV::Ctx &tc_, int px, 
 #pragma unroll
         for (int k = 0; k < 3; ++k) fc[k] = fc[k] + a.global_light[k] * sky[k] * tc[k] * 1.0f;
     } else {
-        F3 normal = h.normal;
-        if (!(len3(h.normal) > 0.0f)) normal = F3{0.0f, 1.0f, 0.0f};
-        F3 hpw{h.point.x / a.voxel_scale, h.point.y / a.voxel_scale, h.point.z / a.voxel_scale};
-        float dist_in_medium = 0.0f + len3(sub3(hpw, gro)) / a.voxel_scale;
-        Decoded hv = decode_leaf(h.h0, h.h1);
-        Decoded lv = decode_leaf(h.p0, h.p1);
+        // normal = length(hitNormal) > 0 ? hitNormal : (0,1,0)  (comp:497); hitNormal is n on h.axis
+        int naxis = h.axis;
+        float nval = h.n;
+        if (!(__builtin_fabsf(h.n) > 0.0f)) { naxis = 1; nval = 1.0f; }
+        // x / 1.0f == x: the divisions by u_voxelScale only cost instructions at the reference's scale of 1
+        F3 hpw = h.point;
+        if (a.voxel_scale != 1.0f) hpw = F3{h.point.x / a.voxel_scale, h.point.y / a.voxel_scale, h.point.z / a.voxel_scale};
+        // distanceInMedium only feeds the absorption term, which needs mediumDensity > 0 (comp:501,512)
+        float dist_in_medium = 0.0f;
+        if (medium_density > 0.0f) dist_in_medium = 0.0f + len3(sub3(hpw, gro)) / a.voxel_scale;
+        Decoded hv = decode_leaf(unorm, h.h0, h.h1);
+        Decoded lv = decode_leaf(unorm, h.p0, h.p1);
         if (hv.c[3] <= 0.0f) { hv.p[0] = 1.0f; hv.p[1] = 0.0f; hv.p[2] = 0.0f; }
         if (lv.c[3] <= 0.0f) {
             if (start_iof > 0.0f) { lv.p[0] = 0.0f; lv.p[1] = 0.0f; lv.p[2] = 0.0f; }
@@ -197,13 +204,16 @@ VRT_DEV void trace_pixel(const KArgs &a, const typename TRAV::Ctx &tc_, int px, 
         if (h.map.x == a.highlighted[0] && h.map.y == a.highlighted[1] && h.map.z == a.highlighted[2]) {
             sc[0] = 1.0f - sc[0]; sc[1] = 1.0f - sc[1]; sc[2] = 1.0f - sc[2]; sc[3] = 1.0f;
         }
-        float cosi = dot3(ray_dir, normal);
-        if (cosi > 0.0f) normal = F3{-normal.x, -normal.y, -normal.z};
+        // dot products with an axis normal: (a*0 + b*n) + c*0 == b*n up to the sign of a zero, which neither
+        // the comparisons nor the final rgba8 rounding can see (comp:522-524,537)
+        float cosi = comp(ray_dir, naxis) * nval;
+        if (cosi > 0.0f) nval = -nval;
+        F3 normal{naxis == 0 ? nval : 0.0f, naxis == 1 ? nval : 0.0f, naxis == 2 ? nval : 0.0f};
         F3 light{a.light_dir[0], a.light_dir[1], a.light_dir[2]};
-        float ndotl = fmax_c(dot3(normal, light), 0.0f);
+        float ndotl = fmax_c(nval * comp(light, naxis), 0.0f);
         if (sc[3] >= 1.0f) {  // depth 0, first hit (comp:539-544)
             int lin = h.map.x + a.tex_dim * (h.map.y + a.tex_dim * h.map.z);
-            voxel_id = lin * 6 + face_index(h.normal);
+            voxel_id = lin * 6 + face_index(h.axis, h.n);
             pixel_dist = (int)len3(sub3(hpw, ray_origin));
         }
         if (sc[3] < 1.0f) {  // translucent first hit: direct-lit fallback (comp:548-553)
@@ -241,8 +251,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
     extern __shared__ __attribute__((aligned(16))) uint2 lds_dyn[];
     constexpr int TH = 64 / TW;
     constexpr int WAVES = BLOCK / 64;
+    __shared__ float unorm[256];  // (float)b / 255.0f for every byte b (comp:173-177), one correctly rounded division each
+    for (int i = threadIdx.x; i < 256; i += BLOCK) unorm[i] = (float)i / 255.0f;
     typename TRAV::Ctx tc_;
     TRAV::template block_init<BLOCK>(a, lds_dyn, tc_);
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int tiles_x = (a.width + TW - 1) / TW;
@@ -257,7 +270,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
             int py = a.row0 + (j / a.tile_rows) * a.row_stride + (j % a.tile_rows);
             uint32_t rgba;
             int2 idd;
-            trace_pixel<MODE, TRAV>(a, tc_, px, py, rgba, idd);
+            trace_pixel<MODE, TRAV>(a, tc_, unorm, px, py, rgba, idd);
             size_t o = (size_t)(a.compact ? j : py) * (size_t)a.width + (size_t)px;
             if (a.out_rgba) a.out_rgba[o] = rgba;
             if (a.out_id) a.out_id[o] = idd;

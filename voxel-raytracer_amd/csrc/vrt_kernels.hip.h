@@ -231,7 +231,7 @@ struct Trav {
             go = inw && !hit && i < 1024;
         } while (go);
         const float n = -comp(sd, axis);
-        h.normal = F3{axis == 0 ? n : 0.0f, axis == 1 ? n : 0.0f, axis == 2 ? n : 0.0f};
+        h.axis = axis; h.n = n;
         h.map = mp; h.point = rp; h.p0 = pw0; h.p1 = pw1; h.h0 = cur.w0; h.h1 = cur.w1;
         return hit;
     }

@@ -102,7 +102,7 @@ struct Trav {
         // medium the ray is currently in: refraction index if (alpha > 0 && props[0] > 0)
         float cur_ref = refraction_of(cur.w1);
         bool cur_solid = (cur.w0 >> 24) != 0u && cur_ref > 0.0f;
-        h.normal = F3{0.0f, 0.0f, 0.0f};
+        h.axis = 0; h.n = 0.0f;
         for (int i = 0; i < 1024; ++i) {
             F3 tp;
             tp.x = (dir.x > 0.0f ? (float)cur.mx.x : (float)cur.mn.x) - rp.x;
@@ -113,7 +113,7 @@ struct Trav {
             int axis = (tx < ty) ? ((tx < tz) ? 0 : 2) : ((ty < tz) ? 1 : 2);
             float sd = sign_c(comp(dir, axis));
             float n = -sd;
-            h.normal = F3{axis == 0 ? n : 0.0f, axis == 1 ? n : 0.0f, axis == 2 ? n : 0.0f};
+            h.axis = axis; h.n = n;
             rp.x = rp.x + dir.x * t; rp.y = rp.y + dir.y * t; rp.z = rp.z + dir.z * t;
             float push = sd * 0.0001f;
             if (axis == 0) rp.x = rp.x + push; else if (axis == 1) rp.y = rp.y + push; else rp.z = rp.z + push;
