@@ -169,8 +169,17 @@ def main():
             b_algo = 4 * f_local + 12 * W * plan.rows_local
             avg_ms = float(kernel_ms.mean())
             achieved = b_algo / (avg_ms * 1e-3) / 1e9
+            # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc.sh);
+            # counters cannot be read from inside this process, so the committed figure for this exact
+            # workload/variant is quoted, else null
+            traffic = None
+            try:
+                tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                traffic = tr.get(f"{args.map}/{W}x{H}/{args.mode}/variant{args.variant}/gpus{world}", {}).get("bytes")
+            except OSError:
+                pass
             roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "kernel": "trace_kernel", "kernel_avg_ms": round(avg_ms, 5),
                         "algorithmic_bytes_per_launch": b_algo,
                         "compulsory_bytes_per_launch": int(tex.size + 12 * W * plan.rows_local)}
