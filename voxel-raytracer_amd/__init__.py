@@ -151,7 +151,10 @@ class World:
 
     def close(self):
         if getattr(self, "_h", None):
-            host_lib().vrth_world_destroy(self._h)
+            try:
+                host_lib().vrth_world_destroy(self._h)
+            except TypeError:  # interpreter shutdown: module globals already cleared
+                pass
             self._h = None
 
     __del__ = close
