@@ -45,7 +45,7 @@ WORKER = textwrap.dedent("""
             assert np.array_equal(frame_id.numpy(), full_id)
     dist.barrier()
     dist.destroy_process_group()
-    sys.stdout.write(f"rank {rank} ok\\n"); sys.stdout.flush()
+    sys.stdout.write("rank %d ok\\n" % rank); sys.stdout.flush()
 """)
 
 
