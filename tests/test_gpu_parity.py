@@ -168,6 +168,39 @@ def test_custom_world_bounds_and_unit_internal_node(ctx, V, O):
     ctx.set_params(ctx.default_params())
 
 
+def test_world_with_eight_wide_roots_and_a_refused_one(ctx, V, O):
+    """World [-256,256)^3 (side 2^9): the eight octants are separate wide roots and rays cross between them.
+    World [-64,192)^3: too many aligned sub-trees for the root table -> the dispatcher must fall back, silently exact."""
+    from conftest import random_voxels
+    rng = np.random.default_rng(4)
+    xyz, rgba = random_voxels(rng, 5000, -60, 70)
+    for wmin, wmax in [((-256,) * 3, (256,) * 3), ((-64,) * 3, (192,) * 3)]:
+        w = V.World(world_min=wmin, world_max=wmax)
+        w.insert_many(xyz, rgba)
+        tex, dim = w.flatten()
+        W, H = 128, 80
+        ip, iv, cp, _ = V.camera_block((100.5, 90.5, 120.5), -130.0, -30.0, W, H)
+        ctx.upload_octree(tex, dim)
+        ctx.set_camera(ip, iv, cp)
+        p = ctx.default_params()
+        p.world_min[:] = wmin
+        p.world_max[:] = wmax
+        ctx.set_params(p)
+        s = O.make_scene(tex, dim, ip, iv, cp)
+        s.bounds_min[:] = wmin
+        s.bounds_max[:] = wmax
+        for mode in (0, 1):
+            ref_rgba, ref_id, _, st = O.render(s, W, H, mode)
+            assert st["hits"] > 500
+            for v in (0, 1, 4, 13):
+                ctx.set_variant(v)
+                rgba_, idd = ctx.dispatch(W, H, mode)
+                _assert_same(rgba_, ref_rgba, f"world {wmin} mode {mode} variant {v} rgba8")
+                _assert_same(idd, ref_id, f"world {wmin} mode {mode} variant {v} id/dist")
+    ctx.set_variant(0)
+    ctx.set_params(ctx.default_params())
+
+
 def test_materials_highlight_and_translucent_fallback(ctx, V, O):
     """Emissive, translucent and highlighted voxels + a camera sitting inside a translucent medium."""
     w = V.World()

@@ -241,3 +241,59 @@ def test_layout_walk_equals_texel_walk(V, O, product_scenes):
             w0, w1 = got[1]
             assert (w0 & 0xff, (w0 >> 8) & 0xff, (w0 >> 16) & 0xff, w0 >> 24) == (leaf[0], leaf[1], leaf[2], leaf[7])
             assert (w1 & 0xff, (w1 >> 8) & 0xff, (w1 >> 16) & 0xff) == (leaf[4], leaf[5], leaf[6])
+
+
+@pytest.mark.parametrize("name", ["dragon", "monu9", "nature"])
+def test_wide_layout_answers_like_the_texel_stream(V, O, product_scenes, name):
+    """The 64-cell wide layout (what the default kernels read) returns octreeFind's result: leaf words + node AABB."""
+    tex, dim = product_scenes[name]
+    rng = np.random.default_rng(21)
+    pts = np.concatenate([rng.integers(-6, 132, size=(6000, 3)), rng.integers(-1023, 1024, size=(1500, 3)),
+                          np.array([[0, 0, 0], [-1, 0, 0], [1023, 1023, 1023], [-1023, -1023, -1023], [512, 0, 3]])])
+    res = V.wide_find(tex, pts)
+    assert res is not None
+    out, (n_nodes, n_roots) = res
+    assert n_roots == 1 and n_nodes > 500
+    s = O.make_scene(tex, dim, np.eye(4, dtype=np.float32).ravel(), np.eye(4, dtype=np.float32).ravel(), [0, 0, 0, 1])
+    leaf = (C.c_uint8 * 8)()
+    mn, mx = (C.c_int32 * 3)(), (C.c_int32 * 3)()
+    for p, o in zip(pts, out):
+        f = O.lib().o_find_point(C.byref(s), (C.c_int32 * 3)(*[int(v) for v in p]), leaf, mn, mx)
+        w0 = (leaf[0] | leaf[1] << 8 | leaf[2] << 16 | leaf[7] << 24) if f else 0
+        w1 = (leaf[4] | leaf[5] << 8 | leaf[6] << 16) if f else 0
+        assert (int(o[0]), int(o[1])) == (w0, w1), p
+        assert list(o[2:5].view(np.int32)) == list(mn) and list(o[5:8].view(np.int32)) == list(mx), p
+
+
+def test_wide_layout_other_world_bounds_and_refusals(V, O):
+    rng = np.random.default_rng(4)
+    xyz, rgba = random_voxels(rng, 3000, -60, 70)
+    w = V.World(world_min=(-256, -256, -256), world_max=(256, 256, 256))   # side 2^9: its eight octants are the wide roots
+    w.insert_many(xyz, rgba)
+    tex, dim = w.flatten()
+    pts = rng.integers(-256, 256, size=(4000, 3))
+    out, (n_nodes, n_roots) = V.wide_find(tex, pts, (-256, -256, -256), (256, 256, 256))
+    assert n_roots == 8
+    s = O.make_scene(tex, dim, np.eye(4, dtype=np.float32).ravel(), np.eye(4, dtype=np.float32).ravel(), [0, 0, 0, 1])
+    s.bounds_min[:] = (-256, -256, -256)
+    s.bounds_max[:] = (256, 256, 256)
+    leaf = (C.c_uint8 * 8)()
+    mn, mx = (C.c_int32 * 3)(), (C.c_int32 * 3)()
+    for p, o in zip(pts, out):
+        f = O.lib().o_find_point(C.byref(s), (C.c_int32 * 3)(*[int(v) for v in p]), leaf, mn, mx)
+        w0 = (leaf[0] | leaf[1] << 8 | leaf[2] << 16 | leaf[7] << 24) if f else 0
+        w1 = (leaf[4] | leaf[5] << 8 | leaf[6] << 16) if f else 0
+        assert (int(o[0]), int(o[1])) == (w0, w1) and list(o[2:5].view(np.int32)) == list(mn) and list(o[5:8].view(np.int32)) == list(mx)
+    # odd-sized world with voxels on both sides of every split: several aligned sub-trees -> still exact or refused
+    w2 = V.World()
+    xyz2, rgba2 = random_voxels(rng, 4000, -900, 900)
+    w2.insert_many(xyz2, rgba2)
+    tex2, dim2 = w2.flatten()
+    pts2 = np.concatenate([xyz2[:1500], rng.integers(-1023, 1024, size=(1500, 3))])
+    res = V.wide_find(tex2, pts2)
+    if res is not None:
+        s2 = O.make_scene(tex2, dim2, np.eye(4, dtype=np.float32).ravel(), np.eye(4, dtype=np.float32).ravel(), [0, 0, 0, 1])
+        for p, o in zip(pts2, res[0]):
+            f = O.lib().o_find_point(C.byref(s2), (C.c_int32 * 3)(*[int(v) for v in p]), leaf, mn, mx)
+            w0 = (leaf[0] | leaf[1] << 8 | leaf[2] << 16 | leaf[7] << 24) if f else 0
+            assert int(o[0]) == w0 and list(o[2:5].view(np.int32)) == list(mn) and list(o[5:8].view(np.int32)) == list(mx)

@@ -266,6 +266,26 @@ def build_layout(texels):
     return rec, info
 
 
+def wide_find(texels, points, world_min=(-1023, -1023, -1023), world_max=(1024, 1024, 1024)):
+    """Host-only: point queries through the wide (64-cell) layout the default kernels read.
+    -> (uint32[n,8] = w0, w1, mn[3], mx[3], (wide nodes, roots)), or None when the scene has no wide form."""
+    L = hip_lib()
+    L.vrt_debug_wide_find.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p,
+                                      C.c_size_t, C.c_void_p, C.c_void_p]
+    t = np.ascontiguousarray(texels, np.uint8)
+    pts = np.ascontiguousarray(points, np.int32).reshape(-1, 3)
+    out = np.zeros((pts.shape[0], 8), np.uint32)
+    stats = np.zeros(2, np.uint32)
+    r = L.vrt_debug_wide_find(t.ctypes.data if t.size else None, t.size, (C.c_int32 * 3)(*world_min),
+                              (C.c_int32 * 3)(*world_max), pts.ctypes.data, pts.shape[0], out.ctypes.data,
+                              stats.ctypes.data)
+    if r == -5:
+        return None
+    if r != 0:
+        raise VrtError(f"vrt_debug_wide_find failed ({r})")
+    return out, (int(stats[0]), int(stats[1]))
+
+
 class Context:
     """One GPU's dispatch context (vrt_ctx)."""
 
