@@ -107,16 +107,15 @@ def main():
     plan = shd.ShardPlan(W, H, args.tile_rows, rank, world)
     local = plan.local_buffer(dev)
     p_rgba, p_id = plan.pointers(local)
-    gathered = [torch.empty_like(local) for _ in range(world)] if (rank == 0 and world > 1) else None
-    frame_rgba = torch.zeros((H, W), dtype=torch.int32, device=dev) if rank == 0 else None
-    frame_id = torch.zeros((H, W, 2), dtype=torch.int32, device=dev) if rank == 0 else None
-    row_index = plan.frame_index(dev) if rank == 0 else None
+    gathered = plan.gather_buffer(dev) if (rank == 0 and world > 1) else None
+    store = plan.frame_store(dev) if rank == 0 else None
+    index = plan.scatter_index(dev) if rank == 0 else None
     stream = torch.cuda.current_stream(dev).cuda_stream  # launch on torch's stream so the gather orders after it
 
     def step():
         ctx.dispatch_shard(W, H, args.tile_rows, rank, world, mode, p_rgba, p_id, stream)
         if world > 1:
-            shd.gather_frame(plan, local, gathered, frame_rgba, frame_id, row_index)
+            shd.gather_frame(plan, local, gathered, store, index)
 
     def fence():
         if world > 1:
@@ -141,7 +140,7 @@ def main():
 
     # frame assembled once more outside the timed region for the self-check (N=1 path has no gather in step())
     if world == 1:
-        shd.gather_frame(plan, local, None, frame_rgba, frame_id, row_index)
+        shd.gather_frame(plan, local, None, store, index)
     torch.cuda.synchronize(dev)
 
     if rank == 0:
@@ -149,6 +148,7 @@ def main():
         key = {"dragon": "dragon_1080p", "monu9": "monu9_720p", "nature": "nature_4k"}[args.map] + f"/mode{mode}"
         g = frames.get(key)
         known = g is not None and (g["width"], g["height"]) == (W, H)
+        frame_rgba, frame_id = plan.frame_views(store)
         rgba_host = frame_rgba.cpu().numpy().view("uint8").reshape(H, W, 4)
         id_host = frame_id.cpu().numpy()
         check = None

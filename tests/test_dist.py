@@ -35,12 +35,12 @@ WORKER = textwrap.dedent("""
             rm = plan.rows_max
             local[: rm * W].view(rm, W)[: len(rows)] = torch.from_numpy(full_rgba[rows].copy().view(np.int32).reshape(len(rows), W))
             local[rm * W:].view(rm, W, 2)[: len(rows)] = torch.from_numpy(full_id[rows].copy())
-        gathered = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
-        frame_rgba = torch.zeros((H, W), dtype=torch.int32) if rank == 0 else None
-        frame_id = torch.zeros((H, W, 2), dtype=torch.int32) if rank == 0 else None
-        idx = plan.frame_index("cpu") if rank == 0 else None
-        shd.gather_frame(plan, local, gathered, frame_rgba, frame_id, idx)
+        gathered = plan.gather_buffer("cpu") if rank == 0 else None
+        store = plan.frame_store("cpu") if rank == 0 else None
+        idx = plan.scatter_index("cpu") if rank == 0 else None
+        shd.gather_frame(plan, local, gathered, store, idx)
         if rank == 0:
+            frame_rgba, frame_id = plan.frame_views(store)
             assert np.array_equal(frame_rgba.numpy().view(np.uint8).reshape(H, W, 4), full_rgba)
             assert np.array_equal(frame_id.numpy(), full_id)
     dist.barrier()

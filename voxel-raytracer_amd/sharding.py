@@ -2,13 +2,15 @@
 
 Pixels are independent, so the frame is cut into tiles of `tile_rows` rows dealt round-robin to the
 ranks (sky rows are several times cheaper than model rows; interleaving balances them). Each rank
-traces its tiles into ONE compact device buffer laid out as
+traces its tiles into ONE compact device buffer of int32 words laid out as
 
-    [ rgba8 block : rows_max * W int32 ][ id/dist block : rows_max * W * 2 int32 ]
+    [ rgba8 block : rows_max * W ][ id/dist block : rows_max * 2W ]        (3 * rows_max "rows" of W words)
 
 so the only exchange step of the path -- the gather of finished rows to rank 0 -- is a single
-collective per frame (RCCL over xGMI with backend "nccl", gloo in the CPU tests). Rank 0 then
-un-interleaves the rows into frame order with one index_copy per image.
+collective per frame (RCCL over xGMI with backend "nccl", gloo in the CPU tests). Rank 0 receives
+straight into one [world, 3 * rows_max, W] tensor and un-interleaves it with ONE index_copy_ into a
+[3H + 1, W] frame store whose first H rows are the rgba8 image and next 2H rows the (voxelID, dist)
+image (row 3H swallows the padding rows of ranks that own fewer rows).
 """
 import torch
 import torch.distributed as dist
@@ -36,26 +38,41 @@ class ShardPlan:
         base = buf.data_ptr()
         return base, base + self.rows_max * self.width * 4
 
-    def frame_index(self, device):
-        """for rank 0: per source rank, the frame rows its compact rows land on"""
-        return [torch.tensor(r, dtype=torch.long, device=device) for r in self.rows_of]
+    # ---- rank 0 side -------------------------------------------------------------------------
+    def gather_buffer(self, device):
+        """[world, words] receive tensor; row r is rank r's compact buffer"""
+        return torch.zeros((self.world, self.words), dtype=torch.int32, device=device)
+
+    def frame_store(self, device):
+        """[3H + 1, W] int32: rows [0,H) rgba8, rows [H,3H) id/dist (two W-word rows per pixel row), row 3H scratch"""
+        return torch.zeros((3 * self.height + 1, self.width), dtype=torch.int32, device=device)
+
+    def frame_views(self, store):
+        H, W = self.height, self.width
+        return store[:H], store[H:3 * H].view(H, W, 2)
+
+    def scatter_index(self, device):
+        """destination row in the frame store of every W-word row of the gathered tensor"""
+        H, rm = self.height, self.rows_max
+        idx = torch.full((self.world, 3 * rm), 3 * H, dtype=torch.long)
+        for r, rows in enumerate(self.rows_of):
+            for j, y in enumerate(rows):
+                idx[r, j] = y
+                idx[r, rm + 2 * j] = H + 2 * y
+                idx[r, rm + 2 * j + 1] = H + 2 * y + 1
+        return idx.reshape(-1).to(device)
 
 
-def gather_frame(plan, local, gathered, frame_rgba, frame_id, row_index, group=None):
-    """Gathers every rank's buffer to rank 0 and scatters the rows into frame order there.
+def gather_frame(plan, local, gathered, store, index, group=None):
+    """Gathers every rank's compact buffer to rank 0 and scatters the rows into the frame store there.
 
-    local: this rank's buffer; gathered: (rank 0) list of `world` buffers or None;
-    frame_rgba [H, W] int32, frame_id [H, W, 2] int32 (rank 0)."""
+    local: this rank's buffer [words]; gathered: rank 0's [world, words] tensor (None elsewhere);
+    store/index: rank 0's frame store and scatter index (None elsewhere)."""
     if plan.world > 1:
-        dist.gather(local, gathered if plan.rank == 0 else None, dst=0, group=group)
+        dist.gather(local, list(gathered.unbind(0)) if plan.rank == 0 else None, dst=0, group=group)
+        src = gathered
     else:
-        gathered = [local]
+        src = local
     if plan.rank != 0:
         return
-    W, rm = plan.width, plan.rows_max
-    for r, buf in enumerate(gathered):
-        n = len(plan.rows_of[r])
-        if n == 0:
-            continue
-        frame_rgba.index_copy_(0, row_index[r], buf[: rm * W].view(rm, W)[:n])
-        frame_id.index_copy_(0, row_index[r], buf[rm * W:].view(rm, W, 2)[:n])
+    store.index_copy_(0, index, src.view(plan.world * 3 * plan.rows_max, plan.width))
