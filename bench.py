@@ -24,6 +24,7 @@ POSES = {  # framing poses of SURVEY.md 8(d): x, y, z, yaw, pitch
     "dragon": (63.5, 60.5, 140.5, -90.0, -10.0),
     "monu9": (48.5, 60.5, 170.5, -90.0, -12.0),
     "nature": (60.5, 80.5, 200.5, -90.0, -20.0),
+    "terrain": (512.5, 420.5, 1000.5, -90.0, -20.0),  # config 4: procedural 1024^2 heightfield shell
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -91,7 +92,9 @@ def main():
 
     # host side of the path: .vox -> octree -> texel stream; camera block (all through the product library)
     wld = V.World()
-    if not wld.load_vox(os.path.join(ROOT, "tests", "golden", "maps", args.map + ".vox")):
+    if args.map == "terrain":
+        wld.fill_terrain(1024, 1337)
+    elif not wld.load_vox(os.path.join(ROOT, "tests", "golden", "maps", args.map + ".vox")):
         raise SystemExit("cannot load the scene fixture")
     tex, dim = wld.flatten()
     pose = POSES[args.map]
@@ -145,7 +148,7 @@ def main():
 
     if rank == 0:
         frames = json.load(open(os.path.join(ROOT, "tests", "golden", "frames.json")))["frames"]
-        key = {"dragon": "dragon_1080p", "monu9": "monu9_720p", "nature": "nature_4k"}[args.map] + f"/mode{mode}"
+        key = {"dragon": "dragon_1080p", "monu9": "monu9_720p", "nature": "nature_4k"}.get(args.map, "-") + f"/mode{mode}"
         g = frames.get(key)
         known = g is not None and (g["width"], g["height"]) == (W, H)
         frame_rgba, frame_id = plan.frame_views(store)
@@ -188,7 +191,8 @@ def main():
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32",
-            "data": f"tests/golden/maps/{args.map}.vox scene fixture, fixed synthetic camera pose",
+            "data": (f"tests/golden/maps/{args.map}.vox scene fixture" if args.map != "terrain" else
+                     "procedural 1024x1024 heightfield (vrth_world_fill_terrain, seed 1337)") + ", fixed synthetic camera pose",
             "config": {"workload": f"{args.map}.vox {W}x{H} {args.mode} rays, pose {pose}", "mode": args.mode,
                        "sharding": f"interleaved {args.tile_rows}-row tiles over {world} rank(s), gather to rank 0 in-step",
                        "variant": args.variant},

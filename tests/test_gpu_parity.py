@@ -201,6 +201,28 @@ def test_world_with_eight_wide_roots_and_a_refused_one(ctx, V, O):
     ctx.set_params(ctx.default_params())
 
 
+def test_procedural_terrain_config4(ctx, V, O):
+    """BASELINE config 4 stand-in: 1024x1024 heightfield shell (6.7 M texels, close to the 2^23 pointer limit)."""
+    w = V.World()
+    w.fill_terrain(1024, 1337)
+    tex, dim = w.flatten()
+    assert 4_000_000 < tex.size // 4 < 2 ** 23
+    W, H = 160, 90
+    cam = _setup(ctx, V, tex, dim, (512.5, 420.5, 1000.5, -90.0, -20.0), W, H)
+    for mode in (0, 1):
+        ref_rgba, ref_id, st = _oracle_frame(O, tex, dim, cam, W, H, mode)
+        assert st["hits"] > 0.3 * W * H
+        for v in (0, 1, 4):
+            ctx.set_variant(v)
+            rgba, idd = ctx.dispatch(W, H, mode)
+            _assert_same(rgba, ref_rgba, f"terrain mode {mode} variant {v} rgba8")
+            _assert_same(idd, ref_id, f"terrain mode {mode} variant {v} id/dist")
+    ctx.set_variant(0)
+    # the texel limit itself is enforced
+    with pytest.raises(V.VrtError, match="2\\^23"):
+        ctx.upload_octree(np.zeros(4 * (2 ** 23 + 1), np.uint8), 204)
+
+
 def test_materials_highlight_and_translucent_fallback(ctx, V, O):
     """Emissive, translucent and highlighted voxels + a camera sitting inside a translucent medium."""
     w = V.World()

@@ -12,7 +12,7 @@ import torch  # noqa: E402
 import vrt_import  # noqa: E402
 
 POSES = {"dragon": (63.5, 60.5, 140.5, -90.0, -10.0), "monu9": (48.5, 60.5, 170.5, -90.0, -12.0),
-         "nature": (60.5, 80.5, 200.5, -90.0, -20.0)}
+         "nature": (60.5, 80.5, 200.5, -90.0, -20.0), "terrain": (512.5, 420.5, 1000.5, -90.0, -20.0)}
 
 
 def main():
@@ -26,7 +26,10 @@ def main():
     args = ap.parse_args()
     V = vrt_import.vrt()
     w = V.World()
-    assert w.load_vox(os.path.join(ROOT, "tests/golden/maps", args.map + ".vox"))
+    if args.map == "terrain":
+        w.fill_terrain(1024, 1337)
+    else:
+        assert w.load_vox(os.path.join(ROOT, "tests/golden/maps", args.map + ".vox"))
     tex, dim = w.flatten()
     W, H = args.width, args.height
     p = POSES[args.map]

@@ -219,19 +219,32 @@ int vrth_make_custom_vox(uint8_t **out, size_t *out_len) {
     return vrth_encode_vox(64, 64, 64, xyzi.data(), xyzi.size() / 4, pal, out, out_len);
 }
 
-// Config 4 stand-in: size x size heightfield, surface band 8 voxels thick:
-// top layer dirt, bottom two stone, grass between (colours/materials of src/main.cpp:220-259).
+// Config 4 stand-in: size x size heightfield as a watertight one-voxel shell (each column reaches down to its
+// lowest neighbour; grass on top, dirt, stone; colours/materials of src/main.cpp:220-259). A shell, not a
+// filled band: the flattened tree of a 1024^2 field must stay under the format's 2^23-texel pointer limit.
 int vrth_world_fill_terrain(vrth_world *w, int size, int seed) {
     if (!w || size < 1 || size > 1024) return -1;
     const Noise2D noise((uint32_t)seed);
+    std::vector<int> height((size_t)size * size);
     for (int z = 0; z < size; ++z)
         for (int x = 0; x < size; ++x) {
-            double n = 0.6 * noise.at(x * 0.01, z * 0.01) + 0.3 * noise.at(x * 0.031, z * 0.031) + 0.1 * noise.at(x * 0.09, z * 0.09);
+            const double n = 0.6 * noise.at(x * 0.01, z * 0.01) + 0.35 * noise.at(x * 0.031, z * 0.031) + 0.05 * noise.at(x * 0.09, z * 0.09);
             int h = (int)((n + 1.0) * 33.0 * 4.0) + 120;
-            if (h > 1000) h = 1000;
-            int lo = h - 8 < 20 ? 20 : h - 8;
+            height[(size_t)z * size + x] = h > 1000 ? 1000 : h;
+        }
+    for (int z = 0; z < size; ++z)
+        for (int x = 0; x < size; ++x) {
+            const int h = height[(size_t)z * size + x];
+            int lo = h - 1;  // watertight shell: reach down to the lowest 4-neighbour column top
+            const int nx[4] = {x - 1, x + 1, x, x}, nz[4] = {z, z, z - 1, z + 1};
+            for (int k = 0; k < 4; ++k)
+                if (nx[k] >= 0 && nx[k] < size && nz[k] >= 0 && nz[k] < size) {
+                    const int hn = height[(size_t)nz[k] * size + nx[k]];
+                    if (hn < lo) lo = hn;
+                }
+            if (lo < 20) lo = 20;
             for (int y = lo; y < h; ++y) {
-                int kind = (y == h - 1) ? 1 : (y < lo + 2 ? 5 : 0);
+                const int kind = (y == h - 1) ? 0 : (y >= h - 3 ? 1 : 5);  // grass top, dirt, then stone
                 octree_insert(w->root, VoxelObjCreate(voxels[kind], voxelColors[kind], iv3(x, y, z)));
             }
         }
