@@ -74,9 +74,32 @@ def test_det_exp_matches_oracle(ctx, O):
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
+def test_full_mode_math_conventions_match_oracle(ctx, O):
+    """The polynomial sin/cos/pow standing in for GLSL's transcendentals, floor-to-int and rand()'s uint->float."""
+    L = O.lib()
+    phi = np.linspace(0.0, 6.2832, 30001).astype(np.float32)
+    ref_s = np.array([L.o_det_sinf(float(v)) for v in phi], np.float32)
+    ref_c = np.array([L.o_det_cosf(float(v)) for v in phi], np.float32)
+    assert np.array_equal(ctx.debug_math(10, phi, phi).view(np.uint32), ref_s.view(np.uint32))
+    assert np.array_equal(ctx.debug_math(11, phi, phi).view(np.uint32), ref_c.view(np.uint32))
+    x = np.linspace(0.0, 1.0, 20001).astype(np.float32)
+    five = np.full_like(x, 5.0)
+    ref_p = np.array([L.o_det_powf(float(v), 5.0) for v in x], np.float32)
+    assert np.array_equal(ctx.debug_math(12, x, five).view(np.uint32), ref_p.view(np.uint32))
+    rng = np.random.default_rng(3)
+    f = np.concatenate([rng.uniform(-1100, 1100, 50000), [-0.0, 0.0, -1e-40, 1e-40, -1.0, 1.0, -0.99999994, 1023.9999],
+                        np.arange(-8, 8) + 1e-4, np.arange(-8, 8) - 1e-4]).astype(np.float32)
+    assert np.array_equal(ctx.debug_math(13, f, f), np.floor(f).astype(np.int32).astype(np.float32))
+    u = rng.integers(0, 2 ** 32, 50000, dtype=np.uint64).astype(np.uint32)
+    u[:4] = [0, 0xffffffff, 0xffffff7f, 0x80000000]
+    ref_u = (u.astype(np.float32) / np.float32(4294967296.0)).astype(np.float32)
+    assert np.array_equal(ctx.debug_math(14, u.view(np.float32), u.view(np.float32)).view(np.uint32), ref_u.view(np.uint32))
+
+
 @pytest.mark.parametrize("key", ["dragon_256x144/mode0", "dragon_256x144/mode1", "monu9_192x108/mode0",
                                  "monu9_192x108/mode1", "nature_200x112/mode0", "nature_200x112/mode1",
-                                 "dragon_inside_101x67/mode0", "dragon_inside_101x67/mode1"])
+                                 "dragon_inside_101x67/mode0", "dragon_inside_101x67/mode1", "dragon_256x144/mode2",
+                                 "monu9_192x108/mode2", "nature_200x112/mode2", "dragon_inside_101x67/mode2"])
 def test_small_frames_vs_oracle_and_golden(ctx, V, O, golden, product_scenes, key):
     g = golden["frames"]["frames"][key]
     tex, dim = product_scenes[g["map"]]
@@ -94,7 +117,7 @@ def test_small_frames_vs_oracle_and_golden(ctx, V, O, golden, product_scenes, ke
 
 
 @pytest.mark.parametrize("key", ["dragon_1080p/mode0", "dragon_1080p/mode1", "monu9_720p/mode0", "monu9_720p/mode1",
-                                 "dragon_default_720p/mode0", "nature_4k/mode1"])
+                                 "dragon_default_720p/mode0", "nature_4k/mode1", "dragon_720p_full/mode2"])
 def test_full_size_frames_match_committed_hashes(ctx, V, golden, product_scenes, key):
     """BASELINE.json sizes: the oracle's frame hashes were committed by tests/golden/make_golden.py."""
     g = golden["frames"]["frames"][key]
@@ -116,7 +139,7 @@ def test_degenerate_inputs(ctx, V, O, product_scenes):
                          ((-2000.5, 50.5, 30.5, 0.0, 0.0), (32, 18)),      # outside, looking in along +x
                          ((63.5, 60.5, 140.5, -90.0, -10.0), (1, 1)), ((63.5, 60.5, 140.5, -90.0, -10.0), (13, 7))]:
         cam = _setup(ctx, V, tex, dim, pose, W, H)
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             ref_rgba, ref_id, _ = _oracle_frame(O, tex, dim, cam, W, H, mode)
             rgba, idd = ctx.dispatch(W, H, mode)
             _assert_same(rgba, ref_rgba, f"pose {pose} {W}x{H} mode {mode} rgba8")
@@ -156,7 +179,7 @@ def test_custom_world_bounds_and_unit_internal_node(ctx, V, O):
         s = O.make_scene(tex, 3, ip, iv, cp)
         s.bounds_min[:] = (0, 0, 0)
         s.bounds_max[:] = (8, 8, 8)
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             ref_rgba, ref_id, _, st = O.render(s, W, H, mode)
             assert st["hits"] > 20, name
             for v in (0, 1, 2, 13, 15):
@@ -189,7 +212,7 @@ def test_world_with_eight_wide_roots_and_a_refused_one(ctx, V, O):
         s = O.make_scene(tex, dim, ip, iv, cp)
         s.bounds_min[:] = wmin
         s.bounds_max[:] = wmax
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             ref_rgba, ref_id, _, st = O.render(s, W, H, mode)
             assert st["hits"] > 500
             for v in (0, 1, 4, 13):
@@ -209,7 +232,7 @@ def test_procedural_terrain_config4(ctx, V, O):
     assert 4_000_000 < tex.size // 4 < 2 ** 23
     W, H = 160, 90
     cam = _setup(ctx, V, tex, dim, (512.5, 420.5, 1000.5, -90.0, -20.0), W, H)
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         ref_rgba, ref_id, st = _oracle_frame(O, tex, dim, cam, W, H, mode)
         assert st["hits"] > 0.3 * W * H
         for v in (0, 1, 4):
@@ -250,7 +273,7 @@ def test_materials_highlight_and_translucent_fallback(ctx, V, O):
                      ((32.5, 4.5, 10.5, 180.0, 5.0), (-1, -1, -1))]:
         W, H = 96, 64
         cam = _setup(ctx, V, tex, dim, pose, W, H, highlighted=hl)
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             ref_rgba, ref_id, _ = _oracle_frame(O, tex, dim, cam, W, H, mode, highlighted=hl)
             rgba, idd = ctx.dispatch(W, H, mode)
             _assert_same(rgba, ref_rgba, f"materials pose {pose} hl {hl} mode {mode} rgba8")

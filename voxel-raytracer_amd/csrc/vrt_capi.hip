@@ -13,6 +13,7 @@
 #include "vrt_kernels.hip.h"
 #include "vrt_kernels_v1.hip.h"
 #include "vrt_kernels_wide.hip.h"
+#include "vrt_full.hip.h"
 #include "vrt_layout.h"
 
 namespace {
@@ -155,9 +156,8 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
             int mode, void *d_rgba, void *d_id, hipStream_t s) {
     if (!c->have_scene) return fail(c, VRT_E_STATE, "vrt_dispatch: no octree uploaded (call vrt_upload_octree first)");
     if (!c->have_camera) return fail(c, VRT_E_STATE, "vrt_dispatch: no camera set (call vrt_set_camera first)");
-    if (mode != VRT_MODE_PRIMARY && mode != VRT_MODE_PRIMARY_SHADOW)
-        return fail(c, VRT_E_INVALID, mode == VRT_MODE_FULL ? "VRT_MODE_FULL is not implemented by this build"
-                                                             : "unknown mode");
+    if (mode != VRT_MODE_PRIMARY && mode != VRT_MODE_PRIMARY_SHADOW && mode != VRT_MODE_FULL)
+        return fail(c, VRT_E_INVALID, "unknown mode");
     if (n_rows <= 0) return VRT_OK;
     if (!c->analysis_valid) {
         // the world bounds decide which sub-trees are aligned cubes: (re)derive the layouts that depend on them
@@ -189,6 +189,9 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     if (v.trav == 2 && c->unit_internal) {  // precondition of vrt_kernels.hip.h not met: explicit-AABB kernels
         v.trav = 1; v.tw = 8; v.block = 256; v.wpe = 1;
         if (v.lds_cap > 2048) v.lds_cap = 2048;
+    }
+    if (mode == VRT_MODE_FULL) {  // one launch shape per traversal for the full path tracer
+        v.use_lds = false; v.tw = 8; v.block = 256; v.wpe = 1; v.lds_cap = 0;
     }
     vrt::KArgs a;
     std::memcpy(a.inv_proj, c->inv_proj, sizeof a.inv_proj);
@@ -236,8 +239,16 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     const size_t lds_bytes = (size_t)a.lds_records * sizeof(uint2);
     const bool prof = c->profiling && (c->prof_count + 1) * 2 <= c->prof_events.size();
     if (prof) VRT_HIP(c, hipEventRecord(c->prof_events[2 * c->prof_count], s));
-    hipError_t e = (mode == VRT_MODE_PRIMARY) ? launch_mode<0>(v, a, (int)grid, lds_bytes, s)
-                                              : launch_mode<1>(v, a, (int)grid, lds_bytes, s);
+    hipError_t e;
+    if (mode == VRT_MODE_FULL) {
+        // the full path tracer is instantiated for the default traversal and for the explicit-AABB baseline only
+        if (v.trav == 3) e = launch_one<2, vrt::v3::Trav, 8, 256, 1>(a, (int)grid, 0, s);
+        else if (v.trav == 2) e = launch_one<2, vrt::v2::Trav<false>, 8, 256, 1>(a, (int)grid, 0, s);
+        else e = launch_one<2, vrt::v1::Trav<false>, 8, 256, 1>(a, (int)grid, 0, s);
+    } else {
+        e = (mode == VRT_MODE_PRIMARY) ? launch_mode<0>(v, a, (int)grid, lds_bytes, s)
+                                       : launch_mode<1>(v, a, (int)grid, lds_bytes, s);
+    }
     if (e != hipSuccess) return fail(c, VRT_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     if (prof) {
         VRT_HIP(c, hipEventRecord(c->prof_events[2 * c->prof_count + 1], s));
@@ -513,7 +524,10 @@ int vrt_debug_math(vrt_ctx *c, int op, const float *x, const float *y, float *ou
     VRT_HIP(c, hipMalloc((void **)&dout, bytes));
     VRT_HIP(c, hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, c->stream));
     VRT_HIP(c, hipMemcpyAsync(dy, y, bytes, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(vrt::math_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, op, dx, dy, dout, n);
+    if (op >= 10)
+        hipLaunchKernelGGL(vrt::full::math_probe_full_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, op, dx, dy, dout, n);
+    else
+        hipLaunchKernelGGL(vrt::math_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, op, dx, dy, dout, n);
     VRT_HIP(c, hipGetLastError());
     VRT_HIP(c, hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, c->stream));
     VRT_HIP(c, hipStreamSynchronize(c->stream));

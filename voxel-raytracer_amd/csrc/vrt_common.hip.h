@@ -243,6 +243,11 @@ VRT_DEV void trace_pixel(const KArgs &a, const typename TRAV::Ctx &tc_, const fl
     idd = make_int2(voxel_id, pixel_dist);
 }
 
+namespace full {  // MODE 2, defined in vrt_full.hip.h
+template <class TRAV>
+__device__ void trace_pixel_full(const KArgs &a, const typename TRAV::Ctx &tc_, const float *unorm, int px, int py, uint32_t &rgba, int2 &idd);
+}
+
 // One lane per pixel; a wave covers a TW x TH pixel tile (TW*TH == 64) so the 64 rays of a wave
 // stay spatially coherent; workgroups walk tiles with a grid-stride loop.
 // WPE: waves per SIMD the register allocator must leave room for (1 = no constraint beyond BLOCK).
@@ -270,7 +275,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
             int py = a.row0 + (j / a.tile_rows) * a.row_stride + (j % a.tile_rows);
             uint32_t rgba;
             int2 idd;
-            trace_pixel<MODE, TRAV>(a, tc_, unorm, px, py, rgba, idd);
+            if constexpr (MODE == 2) full::trace_pixel_full<TRAV>(a, tc_, unorm, px, py, rgba, idd);
+            else trace_pixel<MODE, TRAV>(a, tc_, unorm, px, py, rgba, idd);
             size_t o = (size_t)(a.compact ? j : py) * (size_t)a.width + (size_t)px;
             if (a.out_rgba) a.out_rgba[o] = rgba;
             if (a.out_id) a.out_id[o] = idd;

@@ -1,0 +1,322 @@
+// vrt_full.hip.h -- VRT_MODE_FULL: the whole of pathTrace (shaders/raytracing.comp:435-622):
+// the 8-deep ray stack with glass reflection/refraction (:546-572), Beer-Lambert absorption
+// (:482-486, :512-516), emission and ambient terms (:574-594), the cosine-weighted diffuse bounce
+// (:596-616) with the PCG-hash RNG (:379-417). The traversal (march / shadow / eye_medium) is the
+// TRAV policy shared with the primary-ray kernels; this file is the shading state machine only.
+//
+// It mirrors the CPU restatement operation for operation (same dot/normalize/cross forms, same
+// polynomial exp/log/sin/cos standing in for GLSL's implementation-defined transcendentals), so the
+// outputs are bit-identical to it. The ray stack lives in private (scratch) memory: 8 x 68 bytes per lane.
+#pragma once
+#include "vrt_common.hip.h"
+
+namespace vrt {
+namespace full {
+
+constexpr int kMaxRays = 8;          // MAX_RAYS  (comp:6)
+constexpr int kBounces = 1;          // BOUNCES   (comp:8)
+constexpr int kIndirectSamples = 1;  // INDIRECT_SAMPLES (comp:7)
+
+struct RayS {            // comp:57-68 without the fields nothing reads (defined, the alpha of the two colours)
+    F3 o, d;
+    float iof, weight;
+    float tint[3];
+    float dim;           // distanceInMedium
+    float mc[3];         // mediumColor.rgb
+    float md;            // mediumDensity
+    int depth;
+};
+
+VRT_DEV F3 cross3(F3 x, F3 y) { return F3{x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y}; }
+
+VRT_DEV float det_logf(float x) {  // x > 0, normal (Cephes logf, plain mul/add)
+    uint32_t u = __float_as_uint(x);
+    int e = (int)(u >> 23) - 126;
+    float m = __uint_as_float((u & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.707106781186547524f) { e -= 1; m = m + m; }
+    m = m - 1.0f;
+    float z = m * m;
+    float y = 7.0376836292e-2f;
+    y = y * m + -1.1514610310e-1f;
+    y = y * m + 1.1676998740e-1f;
+    y = y * m + -1.2420140846e-1f;
+    y = y * m + 1.4249322787e-1f;
+    y = y * m + -1.6668057665e-1f;
+    y = y * m + 2.0000714765e-1f;
+    y = y * m + -2.4999993993e-1f;
+    y = y * m + 3.3333331174e-1f;
+    y = y * m * z;
+    float fe = (float)e;
+    y = y + fe * -2.12194440e-4f;
+    y = y - 0.5f * z;
+    float r = m + y;
+    r = r + fe * 0.693359375f;
+    return r;
+}
+
+VRT_DEV float det_powf(float x, float y) {
+    if (x <= 0.0f) return 0.0f;
+    if (x < 1.17549435e-38f) return 0.0f;
+    return det_expf(y * det_logf(x));
+}
+
+VRT_DEV void det_sincos(float xin, float &s_out, float &c_out) {  // Cephes sinf/cosf octant reduction
+    float x = __builtin_fabsf(xin);
+    int sign_s = xin < 0.0f ? -1 : 1, sign_c = 1;
+    int j = (int)(x * 1.27323954473516f);
+    float y = (float)j;
+    if (j & 1) { j += 1; y = y + 1.0f; }
+    j &= 7;
+    if (j > 3) { sign_s = -sign_s; sign_c = -sign_c; j -= 4; }
+    if (j > 1) sign_c = -sign_c;
+    x = x - y * 0.78515625f;
+    x = x - y * 2.4187564849853515625e-4f;
+    x = x - y * 3.77489497744594108e-8f;
+    float z = x * x;
+    float ps = -1.9515295891e-4f;
+    ps = ps * z + 8.3321608736e-3f;
+    ps = ps * z + -1.6666654611e-1f;
+    ps = ps * z * x + x;
+    float pc = 2.443315711809948e-5f;
+    pc = pc * z + -1.388731625493765e-3f;
+    pc = pc * z + 4.166664568298827e-2f;
+    pc = pc * z * z;
+    pc = pc - 0.5f * z;
+    pc = pc + 1.0f;
+    float sv, cv;
+    if (j == 1 || j == 2) { sv = pc; cv = ps; } else { sv = ps; cv = pc; }
+    s_out = sign_s < 0 ? -sv : sv;
+    c_out = sign_c < 0 ? -cv : cv;
+}
+
+// comp:381-399
+VRT_DEV uint32_t rng_init(int px, int py, int sample) {
+    uint32_t seed = (uint32_t)px + (uint32_t)py * 1920u + 123456u + (uint32_t)sample * 78901u;
+    uint32_t st = seed * 747796405u + 2891336453u;
+    uint32_t w = ((st >> ((st >> 28u) + 4u)) ^ st) * 277803737u;
+    return (w >> 22u) ^ w;
+}
+VRT_DEV float rng_next(uint32_t &state) {
+    state = state * 747796405u + 2891336453u;
+    uint32_t w = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    state = (w >> 22u) ^ w;
+    return (float)state / 4294967296.0f;
+}
+
+// comp:402-417
+VRT_DEV F3 cosine_hemisphere(F3 n, float rx, float ry) {
+    const float kPI = 3.14159265359f;
+    float phi = 2.0f * kPI * ry;
+    float ct = __builtin_sqrtf(rx);
+    float stheta = __builtin_sqrtf(1.0f - rx);
+    float sn, cs;
+    det_sincos(phi, sn, cs);
+    float x = stheta * cs;
+    float z = stheta * sn;
+    F3 up = __builtin_fabsf(n.z) < 0.999f ? F3{0.0f, 0.0f, 1.0f} : F3{1.0f, 0.0f, 0.0f};
+    F3 tangent = normalize3(cross3(up, n));
+    F3 bitangent = cross3(n, tangent);
+    F3 r = add3(add3(scale3(tangent, x), scale3(bitangent, z)), scale3(n, ct));
+    return normalize3(r);
+}
+
+// GLSL refract / reflect
+VRT_DEV F3 refract3(F3 I, F3 N, float eta) {
+    float d = dot3(N, I);
+    float k = 1.0f - eta * eta * (1.0f - d * d);
+    if (k < 0.0f) return F3{0.0f, 0.0f, 0.0f};
+    float f = eta * d + __builtin_sqrtf(k);
+    return sub3(scale3(I, eta), scale3(N, f));
+}
+VRT_DEV F3 reflect3(F3 I, F3 N) { float d = dot3(N, I); return sub3(I, scale3(N, 2.0f * d)); }
+
+VRT_DEV void absorb(float tc[3], float density, float dist, const float mc[3]) {  // comp:482-486,512-516
+    float k = -density * dist;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tc[i] = tc[i] * det_expf(k * (1.0f - mc[i]));
+}
+
+// byte form of a ray's IOF for the byte-based medium test (vrt_kernels.hip.h): every IOF this shader
+// produces is r(b) = (b/255)*3 for a byte b, or 1.0 = r(85); r(b)*85 is within 1e-5 of b
+VRT_DEV uint32_t iof_to_byte(float iof) { return (uint32_t)__builtin_rintf(iof * 85.0f); }
+
+VRT_DEV RayS make_ray(F3 o, F3 d, float iof, float w, const float tint[3], float dim, const float mc[3], float md, int depth) {
+    RayS r;
+    r.o = o; r.d = d; r.iof = iof; r.weight = w;
+    r.tint[0] = tint[0]; r.tint[1] = tint[1]; r.tint[2] = tint[2];
+    r.dim = dim;
+    r.mc[0] = mc[0]; r.mc[1] = mc[1]; r.mc[2] = mc[2];
+    r.md = md; r.depth = depth;
+    return r;
+}
+
+template <class TRAV>
+__device__ void trace_pixel_full(const KArgs &a, const typename TRAV::Ctx &tc_, const float *unorm, int px, int py, uint32_t &rgba, int2 &idd) {
+    const float kPI = 3.14159265359f;
+    const float sky[3] = {0.5f, 0.7f, 1.0f};
+    const float kSun = 3.0f;
+    uint32_t rng = rng_init(px, py, 0);
+    float u = ((float)px / (float)a.width) * 2.0f - 1.0f;
+    float v = ((float)py / (float)a.height) * 2.0f - 1.0f;
+    float view[4];
+    mat_vec(a.inv_proj, u, v, -1.0f, 1.0f, view);
+    if (__builtin_fabsf(view[3]) > 1e-6f) { float w = view[3]; view[0] = view[0] / w; view[1] = view[1] / w; view[2] = view[2] / w; view[3] = view[3] / w; }
+    F3 vd = normalize3(F3{view[0], view[1], view[2]});
+    float wd4[4];
+    mat_vec(a.inv_view, vd.x, vd.y, vd.z, 0.0f, wd4);
+    F3 ray_dir = normalize3(F3{wd4[0], wd4[1], wd4[2]});
+    const F3 ray_origin{a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]};
+
+    int voxel_id = 0;
+    int pixel_dist = a.wmax[0] - a.wmin[0];
+    F3 gro = scale3(ray_origin, a.voxel_scale);
+    uint32_t e0, e1;
+    TRAV::eye_medium(a, tc_, floor_i3(gro), e0, e1);
+    Decoded tv = decode_leaf(unorm, e0, e1);
+    float start_iof = (tv.p[0] > 0.0f && tv.p[0] < 3.0f) ? tv.p[0] : 1.0f;
+    float inv_len = 1.0f / __builtin_sqrtf(dot3(ray_dir, ray_dir));
+    ray_dir = scale3(ray_dir, inv_len);
+
+    RayS stack[kMaxRays];
+    {
+        const float ones[3] = {1.0f, 1.0f, 1.0f};
+        const float gl3[3] = {a.global_light[0], a.global_light[1], a.global_light[2]};
+        stack[0] = make_ray(gro, ray_dir, start_iof, 1.0f, gl3, 0.0f, tv.c[3] > 0.0f ? tv.c : ones, tv.c[3] * 5.0f, 0);
+    }
+    int sp = 1;
+    float fc[3] = {0.0f, 0.0f, 0.0f};
+    const float *gl = a.global_light;
+    const F3 light{a.light_dir[0], a.light_dir[1], a.light_dir[2]};
+
+    while (sp > 0) {
+        RayS r = stack[--sp];
+        Hit h;
+        const bool hit = TRAV::march(a, tc_, r.o, r.d, r.iof, iof_to_byte(r.iof), h);
+        float tc[3] = {r.tint[0], r.tint[1], r.tint[2]};
+        if (!hit && r.depth <= 0) {
+            if (r.dim > 1e-6f && r.md > 0.0f) absorb(tc, r.md, r.dim, r.mc);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) fc[k] = fc[k] + gl[k] * sky[k] * tc[k] * r.weight;
+            continue;
+        } else if (!hit) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) fc[k] = fc[k] + tc[k] * sky[k] * kSun * r.weight / kPI;
+            continue;
+        }
+        const F3 hn{h.axis == 0 ? h.n : 0.0f, h.axis == 1 ? h.n : 0.0f, h.axis == 2 ? h.n : 0.0f};
+        F3 normal = hn;
+        if (!(len3(hn) > 0.0f)) normal = F3{0.0f, 1.0f, 0.0f};
+        const F3 hp = h.point;
+        const F3 hpw{hp.x / a.voxel_scale, hp.y / a.voxel_scale, hp.z / a.voxel_scale};
+        r.dim = r.dim + len3(sub3(hpw, r.o)) / a.voxel_scale;
+        Decoded hv = decode_leaf(unorm, h.h0, h.h1);
+        Decoded last = decode_leaf(unorm, h.p0, h.p1);
+        if (hv.c[3] <= 0.0f) { hv.p[0] = 1.0f; hv.p[1] = 0.0f; hv.p[2] = 0.0f; }
+        if (last.c[3] <= 0.0f) {
+            if (r.iof > 0.0f) { last.p[0] = 0.0f; last.p[1] = 0.0f; last.p[2] = 0.0f; }
+            else { last.p[0] = 1.0f; last.p[1] = 0.0f; last.p[2] = 0.0f; }
+        }
+        float sc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sc[k] = hv.c[3] > 0.0f ? hv.c[k] : last.c[k];
+        float n2 = hv.p[0] > 0.0f ? hv.p[0] : 1.0f;
+        float n1 = last.p[0] > 0.0f ? last.p[0] : 1.0f;
+        const F3 inc = r.d;
+        if (r.dim > 1e-6f && r.md > 0.0f) absorb(tc, r.md, r.dim, r.mc);
+        if (h.map.x == a.highlighted[0] && h.map.y == a.highlighted[1] && h.map.z == a.highlighted[2]) {
+            sc[0] = 1.0f - sc[0]; sc[1] = 1.0f - sc[1]; sc[2] = 1.0f - sc[2]; sc[3] = 1.0f;
+        }
+        const float cosi = dot3(inc, normal);
+        if (cosi > 0.0f) { normal = F3{-normal.x, -normal.y, -normal.z}; const float t = n1; n1 = n2; n2 = t; }
+        const float ndotl = fmax_c(dot3(normal, light), 0.0f);
+
+        if (r.depth == 0 && voxel_id == 0 && sc[3] >= 1.0f) {  // comp:539-544
+            const int lin = h.map.x + a.tex_dim * (h.map.y + a.tex_dim * h.map.z);
+            voxel_id = lin * 6 + face_index(h.axis, h.n);
+            pixel_dist = (int)len3(sub3(hpw, ray_origin));
+        }
+
+        if (r.depth <= 0 && sc[3] < 1.0f) {  // translucent, comp:547-572
+            const F3 refr_dir = refract3(inc, normal, n1 / n2);
+            const float R0 = (n1 - n2) / (n1 + n2) * (n1 - n2) / (n1 + n2);
+            const F3 ninc{-inc.x, -inc.y, -inc.z};
+            const float cos_t = fmax_c(0.0f, dot3(ninc, normal));
+            float fres = R0 + (1.0f - R0) * det_powf(1.0f - cos_t, 5.0f);
+            fres = fmin_c(fmax_c(fres, 0.0f), 1.0f);
+            const bool has_tir = len3(refr_dir) < 0.001f;
+            const float reflect_i = fres;
+            const float refract_i = has_tir ? 0.0f : (1.0f - fres);
+            if (sp == kMaxRays || reflect_i <= 0.001f || refract_i <= 0.001f) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float direct = gl[k] * ndotl;
+                    const float lit = sc[k] * direct;
+                    fc[k] = fc[k] + tc[k] * lit * r.weight;
+                }
+                continue;
+            }
+            if (reflect_i > 0.001f && sp < kMaxRays) {
+                const float rw = r.weight * reflect_i;
+                if (rw > 1e-4f)
+                    stack[sp++] = make_ray(add3(hp, scale3(normal, 1e-4f)), reflect3(inc, normal), n1, rw, tc, r.dim, last.c,
+                                           last.c[3] * 5.0f, r.depth);
+            }
+            if (refract_i > 0.001f && sp < kMaxRays && !has_tir) {
+                stack[sp++] = make_ray(sub3(hp, scale3(normal, 1e-4f)), refr_dir, n2, r.weight * refract_i, tc, 0.0f, hv.c,
+                                       hv.c[3] * 5.0f, r.depth);
+            }
+        } else {  // opaque, comp:573-618
+            const float emission = hv.p[1] * 10.0f;
+            if (emission > 0.0f && r.depth == 0) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) fc[k] = fc[k] + tc[k] * sc[k] * emission * r.weight;
+                continue;
+            } else if (emission > 0.0f) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) fc[k] = fc[k] + tc[k] * sc[k] * emission * r.weight / kPI;
+                continue;
+            }
+            if (r.depth == 0) {
+                const int lit = TRAV::shadow(a, tc_, add3(hp, scale3(normal, 2e-3f)), light);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float direct = gl[k] * (float)lit * ndotl;
+                    fc[k] = fc[k] + direct * sc[k] * tc[k] * r.weight / kPI;
+                }
+            } else {
+                const float amb = fmax_c(1.0f - det_expf(-r.dim / 512.0f), 0.01f);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) fc[k] = fc[k] + amb * sc[k] * tc[k] * r.weight / kPI;
+                continue;
+            }
+            for (int i = 0; i < kIndirectSamples && sp < kMaxRays && r.depth <= kBounces; ++i) {
+                const float rx = rng_next(rng), ry = rng_next(rng);
+                const F3 bd = cosine_hemisphere(normal, rx, ry);
+                const float nw = r.weight / (float)kIndirectSamples;
+                const float tint[3] = {tc[0] * sc[0], tc[1] * sc[1], tc[2] * sc[2]};
+                stack[sp++] = make_ray(add3(hp, scale3(normal, 1e-1f)), bd, n1, nw, tint, 0.0f, last.c, last.c[3] * 5.0f, r.depth + 1);
+            }
+        }
+    }
+    rgba = unorm8(fc[0]) | (unorm8(fc[1]) << 8) | (unorm8(fc[2]) << 16) | (255u << 24);
+    idd = make_int2(voxel_id, pixel_dist);
+}
+
+// exactness probe for the conventions above (ops 10..): out[i] = op(x[i], y[i])
+__global__ void math_probe_full_kernel(int op, const float *x, const float *y, float *out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = x[i], b = y[i], r = 0.0f, s, c;
+    switch (op) {
+        case 10: det_sincos(a, s, c); r = s; break;
+        case 11: det_sincos(a, s, c); r = c; break;
+        case 12: r = det_powf(a, b); break;
+        case 13: { int q; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(q) : "v"(a)); r = (float)q; } break;
+        case 14: r = (float)__float_as_uint(a) / 4294967296.0f; break;  // rand(): uint -> float, RNE
+        default: break;
+    }
+    out[i] = r;
+}
+
+}  // namespace full
+}  // namespace vrt
