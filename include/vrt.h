@@ -112,6 +112,16 @@ int vrt_shard_rows(int height, int tile_rows, int shard, int n_shards);
 int vrt_dispatch_timed(vrt_ctx *ctx, int width, int height, int row_begin, int row_end, int mode,
                        void *d_rgba8, void *d_id_dist, void *stream, int iters, float *ms_out);
 
+/* The display pass that consumes the two images in the reference's frame loop (the fullscreen
+ * quad drawn by src/main.cpp:951-967 with shaders/quad.frag:22-83): ID-aware box blur, radius
+ * clamp(int(200/sqrt(max(1,dist))), 1, 20), only pixels with the centre's voxelID contribute.
+ * DEVICE pointers, full frames (W*H packed rgba8 / W*H int2), stream-ordered; out must not alias in. */
+int vrt_denoise(vrt_ctx *ctx, int width, int height, const void *d_rgba8, const void *d_id_dist, void *d_out_rgba8,
+                void *stream);
+/* the same through HOST buffers, synchronous */
+int vrt_denoise_host(vrt_ctx *ctx, int width, int height, const uint8_t *rgba8, const int32_t *id_dist,
+                     uint8_t *out_rgba8);
+
 /* Per-launch timing of the dispatches that follow: a hipEvent pair is recorded
  * around each kernel launch, on the stream it is launched on, for up to
  * max_launches launches (0 switches it off). vrt_profile_read waits for the

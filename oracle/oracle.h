@@ -117,6 +117,10 @@ void o_scene_defaults(o_scene *s); /* src/main.cpp:478-483,638 */
 void o_render(const o_scene *s, int width, int height, int row0, int row1, int mode,
               uint8_t *rgba8, int32_t *id_dist, uint32_t *fetch_map, o_stats *stats);
 
+/* shaders/quad.frag:22-83 -- the display pass: per-pixel box blur over same-voxelID neighbours, radius
+ * clamp(int(200/sqrt(max(1,dist))), 1, 20). rgba8/id_dist are the two outputs of o_render; out: W*H*4 bytes. */
+void o_denoise(const uint8_t *rgba8, const int32_t *id_dist, int width, int height, uint8_t *out);
+
 /* brute-force point query used to cross-check octreeFind: returns 1 and leaf
  * texels when `pos` is inside a leaf, 0 when empty; node AABB in mn/mx. */
 int o_find_point(const o_scene *s, const int32_t pos[3], uint8_t leaf[8],

@@ -179,6 +179,18 @@ def render(scene, width, height, mode, row0=0, row1=None, want_fetch_map=False):
     return rgba, idd, fm, stats
 
 
+def denoise(rgba, id_dist):
+    """shaders/quad.frag restatement -> rgba8[H,W,4]"""
+    L = lib()
+    L.o_denoise.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    rgba = np.ascontiguousarray(rgba, np.uint8)
+    idd = np.ascontiguousarray(id_dist, np.int32)
+    h, w = rgba.shape[:2]
+    out = np.zeros_like(rgba)
+    L.o_denoise(rgba.ctypes.data, idd.ctypes.data, w, h, out.ctypes.data)
+    return out
+
+
 def fnv1a64(arr):
     a = np.ascontiguousarray(arr)
     return int(lib().o_fnv1a64(a.ctypes.data, a.nbytes))

@@ -644,3 +644,36 @@ int o_find_point(const o_scene *s, const int32_t pos[3], uint8_t leaf[8], int32_
     }
     return 0;
 }
+
+/* ---- display pass: ID-aware box blur (shaders/quad.frag:22-83) ------------------------------------
+ * Conventions: sampler2D on an rgba8 image returns byte/255.0f; the 8-bit framebuffer write is the C7
+ * rounding; sums run in the shader's loop order (y outer, x inner), in fp32. */
+void o_denoise(const uint8_t *rgba8, const int32_t *id_dist, int W, int H, uint8_t *out) {
+    for (int py = 0; py < H; py++)
+        for (int px = 0; px < W; px++) {
+            size_t p = (size_t)py * W + px;
+            int center_id = id_dist[p * 2], center_dist = id_dist[p * 2 + 1];
+            if (center_id == 0) { memcpy(out + p * 4, rgba8 + p * 4, 4); continue; }          /* quad.frag:36-39 */
+            float radius_f = 200.0f / sqrtf((float)(center_dist > 1 ? center_dist : 1));       /* :45 */
+            int R = (int)radius_f;
+            R = R < 1 ? 1 : (R > 20 ? 20 : R);                                                    /* :48 */
+            float sum[3] = {0.0f, 0.0f, 0.0f}, count = 0.0f;
+            for (int y = -R; y <= R; y++)
+                for (int x = -R; x <= R; x++) {
+                    int nx = px + x, ny = py + y;
+                    if (nx < 0 || nx >= W || ny < 0 || ny >= H) continue;                         /* :60-63 */
+                    size_t q = (size_t)ny * W + nx;
+                    if (id_dist[q * 2] == center_id) {                                            /* :67-73 */
+                        sum[0] = sum[0] + (float)rgba8[q * 4 + 0] / 255.0f;
+                        sum[1] = sum[1] + (float)rgba8[q * 4 + 1] / 255.0f;
+                        sum[2] = sum[2] + (float)rgba8[q * 4 + 2] / 255.0f;
+                        count = count + 1.0f;
+                    }
+                }
+            float d = fmax_c(count, 1.0f);                                                        /* :78 */
+            out[p * 4 + 0] = unorm8(sum[0] / d);
+            out[p * 4 + 1] = unorm8(sum[1] / d);
+            out[p * 4 + 2] = unorm8(sum[2] / d);
+            out[p * 4 + 3] = 255;
+        }
+}

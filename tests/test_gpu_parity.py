@@ -246,6 +246,30 @@ def test_procedural_terrain_config4(ctx, V, O):
         ctx.upload_octree(np.zeros(4 * (2 ** 23 + 1), np.uint8), 204)
 
 
+def test_denoise_pass_matches_quad_frag_restatement(ctx, V, O, product_scenes):
+    """shaders/quad.frag (ID-aware box blur, up to 41x41 taps) on the outputs of the full path tracer."""
+    for name, pose, (W, H) in [("dragon", (63.5, 60.5, 140.5, -90.0, -10.0), (256, 144)),
+                                ("dragon", (60.3, 64.7, 75.2, -100.0, -25.0), (200, 120)),    # close-up: radius 20
+                                ("nature", (60.5, 80.5, 600.5, -90.0, -8.0), (177, 99)),      # far: small radii, ragged size
+                                ("monu9", (48.5, 60.5, 170.5, -90.0, -12.0), (64, 64))]:
+        tex, dim = product_scenes[name]
+        _setup(ctx, V, tex, dim, pose, W, H)
+        rgba, idd = ctx.dispatch(W, H, 2)
+        ref = O.denoise(rgba, idd)
+        got = ctx.denoise(rgba, idd)
+        _assert_same(got, ref, f"denoise {name} {W}x{H}")
+        assert np.array_equal(got[idd[..., 0] == 0], rgba[idd[..., 0] == 0])      # sky passes through
+        assert np.any(got != rgba)                                                 # and it did blur something
+    # synthetic ids: negative ids, id present only at the centre, every distance class
+    rng = np.random.default_rng(9)
+    W, H = 150, 90
+    rgba = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8)
+    idd = np.zeros((H, W, 2), np.int32)
+    idd[..., 0] = rng.integers(-3, 4, size=(H, W))
+    idd[..., 1] = rng.choice([0, 1, 2, 50, 99, 100, 101, 400, 2047, 40000], size=(H, W))
+    _assert_same(ctx.denoise(rgba, idd), O.denoise(rgba, idd), "denoise synthetic")
+
+
 def test_materials_highlight_and_translucent_fallback(ctx, V, O):
     """Emissive, translucent and highlighted voxels + a camera sitting inside a translucent medium."""
     w = V.World()

@@ -102,3 +102,30 @@ def test_det_math_is_sane(O):
     assert np.allclose([L.o_det_sinf(float(t)) for t in ts], np.sin(ts), atol=3e-7)
     assert np.allclose([L.o_det_cosf(float(t)) for t in ts], np.cos(ts), atol=3e-7)
     assert abs(L.o_det_powf(0.37, 5.0) - 0.37 ** 5) < 1e-8
+
+
+def test_denoise_restatement_properties(O):
+    """quad.frag restatement: sky passes through, a uniformly coloured voxel face keeps its colour, only same-id
+    pixels mix, and the radius law clamp(int(200/sqrt(max(1,d))),1,20)."""
+    H, W = 40, 60
+    rgba = np.zeros((H, W, 4), np.uint8)
+    rgba[..., 3] = 255
+    idd = np.zeros((H, W, 2), np.int32)
+    rgba[:, :30, :3] = (10, 200, 30)      # sky, id 0
+    rgba[:, 30:, :3] = (90, 90, 90)
+    idd[:, 30:, 0] = 7
+    idd[:, 30:, 1] = 100                  # radius 20
+    rgba[20, 45, :3] = (255, 0, 0)        # one outlier inside the id-7 region
+    out = O.denoise(rgba, idd)
+    assert np.array_equal(out[:, :30], rgba[:, :30])
+    # radius 20: the outlier is one of ~1600 taps, (255-90)/255/1600 is below half an 8-bit step -> invisible
+    assert np.all(out[:, 30:, :3] == 90)
+    # radius law through a single differing id: distance 40000 -> radius 1
+    idd2 = idd.copy()
+    idd2[:, 30:, 1] = 40000
+    out2 = O.denoise(rgba, idd2)
+    changed2 = np.argwhere(np.any(out2[:, 30:, :3] != 90, axis=-1))
+    assert np.all(np.abs(changed2[:, 0] - 20) <= 1) and np.all(np.abs(changed2[:, 1] + 30 - 45) <= 1) and len(changed2) == 9
+    # mean of the 3x3 window around the outlier: (255 + 8*90)/9 etc.
+    c = out2[20, 45, :3]
+    assert abs(int(c[0]) - round((255 + 8 * 90) / 9)) <= 1 and abs(int(c[1]) - round(8 * 90 / 9)) <= 1

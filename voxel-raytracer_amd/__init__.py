@@ -120,6 +120,8 @@ def hip_lib():
         L.vrt_dispatch_timed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float)]
         L.vrt_synchronize.argtypes = [C.c_void_p]
+        L.vrt_denoise.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vrt_denoise_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vrt_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.vrt_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
         L.vrt_stream.restype = C.c_void_p
@@ -364,6 +366,18 @@ class Context:
         if n < 0:
             self._chk(n)
         return np.array(ms[:n], np.float32)
+
+    def denoise(self, rgba, id_dist):
+        """quad.frag's ID-aware blur through host arrays -> rgba8[H,W,4]."""
+        rgba = np.ascontiguousarray(rgba, np.uint8)
+        idd = np.ascontiguousarray(id_dist, np.int32)
+        h, w = rgba.shape[:2]
+        out = np.zeros_like(rgba)
+        self._chk(self._L.vrt_denoise_host(self._h, w, h, rgba.ctypes.data, idd.ctypes.data, out.ctypes.data))
+        return out
+
+    def denoise_device(self, width, height, d_rgba, d_id, d_out, stream=None):
+        self._chk(self._L.vrt_denoise(self._h, width, height, d_rgba, d_id, d_out, stream))
 
     def synchronize(self):
         self._chk(self._L.vrt_synchronize(self._h))

@@ -14,6 +14,7 @@
 #include "vrt_kernels_v1.hip.h"
 #include "vrt_kernels_wide.hip.h"
 #include "vrt_full.hip.h"
+#include "vrt_denoise.hip.h"
 #include "vrt_layout.h"
 
 namespace {
@@ -476,6 +477,46 @@ int vrt_dispatch_timed(vrt_ctx *c, int width, int height, int row_begin, int row
         for (int i = 0; i < iters; ++i) VRT_HIP(c, hipEventElapsedTime(&ms_out[i], ev[2 * i], ev[2 * i + 1]));
     for (auto &e : ev) (void)hipEventDestroy(e);
     return rc;
+}
+
+int vrt_denoise(vrt_ctx *c, int width, int height, const void *d_rgba8, const void *d_id_dist, void *d_out_rgba8, void *stream) {
+    int r = check_frame(c, width, height);
+    if (r) return r;
+    if (!d_rgba8 || !d_id_dist || !d_out_rgba8 || d_rgba8 == d_out_rgba8) return fail(c, VRT_E_INVALID, "vrt_denoise: null or aliased buffers");
+    VRT_HIP(c, hipSetDevice(c->device));
+    vrt::denoise::Args a;
+    a.rgba = (const uint32_t *)d_rgba8;
+    a.id = (const int2 *)d_id_dist;
+    a.out = (uint32_t *)d_out_rgba8;
+    a.width = width;
+    a.height = height;
+    const dim3 grid((unsigned)((width + vrt::denoise::kTile - 1) / vrt::denoise::kTile),
+                    (unsigned)((height + vrt::denoise::kTile - 1) / vrt::denoise::kTile));
+    hipLaunchKernelGGL(vrt::denoise::denoise_kernel, grid, dim3(vrt::denoise::kTile, vrt::denoise::kTile), 0,
+                       stream ? (hipStream_t)stream : c->stream, a);
+    VRT_HIP(c, hipGetLastError());
+    return VRT_OK;
+}
+
+int vrt_denoise_host(vrt_ctx *c, int width, int height, const uint8_t *rgba8, const int32_t *id_dist, uint8_t *out_rgba8) {
+    int r = check_frame(c, width, height);
+    if (r) return r;
+    if (!rgba8 || !id_dist || !out_rgba8) return fail(c, VRT_E_INVALID, "vrt_denoise_host: null buffer");
+    VRT_HIP(c, hipSetDevice(c->device));
+    const size_t px = (size_t)width * (size_t)height;
+    void *d_in = nullptr, *d_id = nullptr, *d_out = nullptr;
+    VRT_HIP(c, hipMalloc(&d_in, px * 4));
+    VRT_HIP(c, hipMalloc(&d_id, px * 8));
+    VRT_HIP(c, hipMalloc(&d_out, px * 4));
+    VRT_HIP(c, hipMemcpyAsync(d_in, rgba8, px * 4, hipMemcpyHostToDevice, c->stream));
+    VRT_HIP(c, hipMemcpyAsync(d_id, id_dist, px * 8, hipMemcpyHostToDevice, c->stream));
+    r = vrt_denoise(c, width, height, d_in, d_id, d_out, nullptr);
+    if (r == VRT_OK) {
+        VRT_HIP(c, hipMemcpyAsync(out_rgba8, d_out, px * 4, hipMemcpyDeviceToHost, c->stream));
+        VRT_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    (void)hipFree(d_in); (void)hipFree(d_id); (void)hipFree(d_out);
+    return r;
 }
 
 int vrt_synchronize(vrt_ctx *c) {
