@@ -29,6 +29,14 @@ POSES = {  # framing poses of SURVEY.md 8(d): x, y, z, yaw, pitch
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def metric_name():
+    """BASELINE.json's metric string, verbatim."""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except (OSError, KeyError, ValueError):
+        return "Mrays/s at 1920×1080 primary rays; achieved HBM GB/s vs peak"
+
+
 def cpu_baseline(args, tex, dim, cam, budget_s=12.0):
     """Times the CPU restatement (oracle/, a scalar single-thread port of the same traversal) on whole
     frames of the same workload until ~budget_s of CPU work is done. Reported, never the target."""
@@ -69,6 +77,11 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=8)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not bracket each launch with hipEvents (roofline is then omitted); for measuring their cost")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the measured path); gloo only rehearses the N>1 code path on a "
+                         "box whose ranks share one GPU (collective staged through host memory)")
     args = ap.parse_args()
 
     import torch
@@ -84,11 +97,19 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ray-casting path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and local_rank >= n_dev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPU(s) visible (one process per GPU)")
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    via_host = args.backend == "gloo"
 
     # host side of the path: .vox -> octree -> texel stream; camera block (all through the product library)
     wld = V.World()
@@ -102,7 +123,7 @@ def main():
     ip, iv, cp, _ = V.camera_block(pose[:3], pose[3], pose[4], W, H)
     mode = V.MODES[args.mode]
 
-    ctx = V.Context(local_rank)
+    ctx = V.Context(dev_index)
     ctx.set_variant(args.variant)
     ctx.upload_octree(tex, dim)
     ctx.set_camera(ip, iv, cp)
@@ -118,7 +139,7 @@ def main():
     def step():
         ctx.dispatch_shard(W, H, args.tile_rows, rank, world, mode, p_rgba, p_id, stream)
         if world > 1:
-            shd.gather_frame(plan, local, gathered, store, index)
+            shd.gather_frame(plan, local, gathered, store, index, stage_through_host=via_host)
 
     def fence():
         if world > 1:
@@ -128,7 +149,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    ctx.set_profiling(args.steps)
+    ctx.set_profiling(0 if args.no_kernel_events else args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -137,7 +158,7 @@ def main():
     kernel_ms = ctx.profile_read(args.steps)
     ctx.set_profiling(0)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if via_host else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -187,7 +208,7 @@ def main():
                         "algorithmic_bytes_per_launch": b_algo,
                         "compulsory_bytes_per_launch": int(tex.size + 12 * W * plan.rows_local)}
         out = {
-            "metric": "Mrays/s at 1920x1080 primary rays; achieved HBM GB/s vs peak",
+            "metric": metric_name(),
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32",
@@ -195,7 +216,7 @@ def main():
                      "procedural 1024x1024 heightfield (vrth_world_fill_terrain, seed 1337)") + ", fixed synthetic camera pose",
             "config": {"workload": f"{args.map}.vox {W}x{H} {args.mode} rays, pose {pose}", "mode": args.mode,
                        "sharding": f"interleaved {args.tile_rows}-row tiles over {world} rank(s), gather to rank 0 in-step",
-                       "variant": args.variant},
+                       "variant": args.variant, "collective_backend": args.backend if world > 1 else None},
             "roofline": roofline,
             "pixels_match_oracle_golden": check,
         }

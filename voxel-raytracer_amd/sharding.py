@@ -63,13 +63,22 @@ class ShardPlan:
         return idx.reshape(-1).to(device)
 
 
-def gather_frame(plan, local, gathered, store, index, group=None):
+def gather_frame(plan, local, gathered, store, index, group=None, stage_through_host=False):
     """Gathers every rank's compact buffer to rank 0 and scatters the rows into the frame store there.
 
     local: this rank's buffer [words]; gathered: rank 0's [world, words] tensor (None elsewhere);
-    store/index: rank 0's frame store and scatter index (None elsewhere)."""
+    store/index: rank 0's frame store and scatter index (None elsewhere).
+    stage_through_host: for backends without device-tensor gather (gloo rehearsals of the N>1 path on a
+    box whose ranks share one GPU): the collective runs on host copies."""
     if plan.world > 1:
-        dist.gather(local, list(gathered.unbind(0)) if plan.rank == 0 else None, dst=0, group=group)
+        if stage_through_host and local.is_cuda:
+            host = local.cpu()
+            recv = [torch.empty_like(host) for _ in range(plan.world)] if plan.rank == 0 else None
+            dist.gather(host, recv, dst=0, group=group)
+            if plan.rank == 0:
+                gathered.copy_(torch.stack(recv))
+        else:
+            dist.gather(local, list(gathered.unbind(0)) if plan.rank == 0 else None, dst=0, group=group)
         src = gathered
     else:
         src = local
