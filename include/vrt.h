@@ -127,6 +127,9 @@ int vrt_denoise_host(vrt_ctx *ctx, int width, int height, const uint8_t *rgba8, 
  * max_launches launches (0 switches it off). vrt_profile_read waits for the
  * recorded launches, writes their durations (ms) and returns how many. */
 int vrt_set_profiling(vrt_ctx *ctx, int max_launches);
+/* bracket only every `every`-th launch (default 1): an event pair keeps consecutive launches from
+ * overlapping, so sampling leaves the timed region closer to an unprofiled run */
+int vrt_set_profiling_stride(vrt_ctx *ctx, int every);
 int vrt_profile_read(vrt_ctx *ctx, float *ms_out, int cap);
 
 int vrt_synchronize(vrt_ctx *ctx);

@@ -357,7 +357,9 @@ class Context:
                                              iters, ms))
         return np.array(ms, np.float32)
 
-    def set_profiling(self, max_launches):
+    def set_profiling(self, max_launches, every=1):
+        self._L.vrt_set_profiling_stride.argtypes = [C.c_void_p, C.c_int]
+        self._chk(self._L.vrt_set_profiling_stride(self._h, every))
         self._chk(self._L.vrt_set_profiling(self._h, max_launches))
 
     def profile_read(self, cap=4096):

@@ -78,6 +78,7 @@ struct vrt_ctx {
     bool profiling = false;
     std::vector<hipEvent_t> prof_events;  // 2 per slot
     size_t prof_count = 0;
+    size_t prof_seen = 0, prof_stride = 1;  // every prof_stride-th launch is bracketed
     // host copy of the records: lets the dispatcher check the bit-indexed traversal's precondition
     // against the CURRENT world bounds (they arrive separately, through vrt_set_params)
     std::vector<vrt::Record> host_records;
@@ -238,7 +239,7 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     }
     if (grid < 1) grid = 1;
     const size_t lds_bytes = (size_t)a.lds_records * sizeof(uint2);
-    const bool prof = c->profiling && (c->prof_count + 1) * 2 <= c->prof_events.size();
+    const bool prof = c->profiling && (c->prof_seen++ % c->prof_stride) == 0 && (c->prof_count + 1) * 2 <= c->prof_events.size();
     if (prof) VRT_HIP(c, hipEventRecord(c->prof_events[2 * c->prof_count], s));
     hipError_t e;
     if (mode == VRT_MODE_FULL) {
@@ -530,12 +531,19 @@ int vrt_set_profiling(vrt_ctx *c, int max_launches) {
     if (!c) return VRT_E_INVALID;
     VRT_HIP(c, hipSetDevice(c->device));
     c->prof_count = 0;
+    c->prof_seen = 0;
     c->profiling = max_launches > 0;
     while (c->profiling && c->prof_events.size() < (size_t)max_launches * 2) {
         hipEvent_t e;
         VRT_HIP(c, hipEventCreate(&e));
         c->prof_events.push_back(e);
     }
+    return VRT_OK;
+}
+
+int vrt_set_profiling_stride(vrt_ctx *c, int every) {
+    if (!c || every < 1) return VRT_E_INVALID;
+    c->prof_stride = (size_t)every;
     return VRT_OK;
 }
 
