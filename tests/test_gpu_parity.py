@@ -293,9 +293,14 @@ def test_materials_highlight_and_translucent_fallback(ctx, V, O):
         for y in range(2, 8):
             for z in range(8, 14):
                 w.insert(x, y, z, 0x3c64dc96, 1.33, 0.0, 0.0)   # a block of water to put the camera in
+    for x in range(44, 50):
+        for y in range(2, 8):
+            for z in range(8, 14):
+                w.insert(x, y, z, 0x3c64dc00, 1.33, 0.0, 0.0)   # alpha 0 but refraction 1.33: only startIOF sees it
+    w.insert(10, 1, 10, 0x11223300, 2.0, 1.0, 0.5)               # a lone alpha-0 voxel with every property set
     tex, dim = w.flatten()
     for pose, hl in [((12.3, 14.2, 40.7, -90.0, -15.0), (-1, -1, -1)), ((12.3, 14.2, 40.7, -90.0, -15.0), (5, 0, 20)),
-                     ((32.5, 4.5, 10.5, 180.0, 5.0), (-1, -1, -1))]:
+                     ((32.5, 4.5, 10.5, 180.0, 5.0), (-1, -1, -1)), ((46.5, 4.5, 10.5, 180.0, 5.0), (-1, -1, -1))]:
         W, H = 96, 64
         cam = _setup(ctx, V, tex, dim, pose, W, H, highlighted=hl)
         for mode in (0, 1, 2):

@@ -260,7 +260,7 @@ def test_wide_layout_answers_like_the_texel_stream(V, O, product_scenes, name):
     for p, o in zip(pts, out):
         f = O.lib().o_find_point(C.byref(s), (C.c_int32 * 3)(*[int(v) for v in p]), leaf, mn, mx)
         w0 = (leaf[0] | leaf[1] << 8 | leaf[2] << 16 | leaf[7] << 24) if f else 0
-        w1 = (leaf[4] | leaf[5] << 8 | leaf[6] << 16) if f else 0
+        w1 = ((leaf[4] if leaf[7] else 0) | leaf[5] << 8 | leaf[6] << 16) if f else 0   # refraction byte reads 0 under alpha 0
         assert (int(o[0]), int(o[1])) == (w0, w1), p
         assert list(o[2:5].view(np.int32)) == list(mn) and list(o[5:8].view(np.int32)) == list(mx), p
 
@@ -282,7 +282,7 @@ def test_wide_layout_other_world_bounds_and_refusals(V, O):
     for p, o in zip(pts, out):
         f = O.lib().o_find_point(C.byref(s), (C.c_int32 * 3)(*[int(v) for v in p]), leaf, mn, mx)
         w0 = (leaf[0] | leaf[1] << 8 | leaf[2] << 16 | leaf[7] << 24) if f else 0
-        w1 = (leaf[4] | leaf[5] << 8 | leaf[6] << 16) if f else 0
+        w1 = ((leaf[4] if leaf[7] else 0) | leaf[5] << 8 | leaf[6] << 16) if f else 0   # refraction byte reads 0 under alpha 0
         assert (int(o[0]), int(o[1])) == (w0, w1) and list(o[2:5].view(np.int32)) == list(mn) and list(o[5:8].view(np.int32)) == list(mx)
     # odd-sized world with voxels on both sides of every split: several aligned sub-trees -> still exact or refused
     w2 = V.World()

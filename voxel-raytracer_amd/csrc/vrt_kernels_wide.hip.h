@@ -36,7 +36,11 @@ struct Found {
     I3 plane;                 // per axis: the face of the node found that a ray with signs `dpos` leaves through
 };
 
-VRT_DEV uint32_t medium_byte(uint32_t w0, uint32_t w1) { return (w0 >> 24) != 0u ? (w1 & 0xffu) : 0u; }  // see vrt_kernels.hip.h
+// Medium test on refraction bytes: see medium_byte() in vrt_kernels.hip.h. Here the byte is prepared at
+// build time: every leaf word pair a lookup returns has refraction byte 0 when its alpha byte is 0
+// (wide cells: vrt_layout.cpp; record leaves: descend_generic). Nothing downstream can tell: the shader
+// replaces the properties of an alpha-0 voxel before using them (comp:503-504); only the lookup at the
+// eye reads them unconditionally, and eye_medium() goes to the raw records.
 
 // (int)floor(x) in one instruction
 VRT_DEV int floor_to_int(float x) {
@@ -95,10 +99,36 @@ struct Trav {
             if (!(m & bit)) return true;
             ridx = b + (uint32_t)__builtin_popcount(m & (bit - 1u));
             const uint2 rec = a.nodes[ridx];
-            if (m & (bit << 8)) { f.w0 = rec.x; f.w1 = rec.y; return true; }
+            if (m & (bit << 8)) {  // leaf: like the wide cells, report refraction byte 0 when alpha == 0
+                f.w0 = rec.x;
+                f.w1 = (rec.x >> 24) != 0u ? rec.y : (rec.y & 0xffffff00u);
+                return true;
+            }
             m = rec.x; b = rec.y;
         }
         return true;  // deeper than the uploader allows: treated as empty
+    }
+
+    // The lookup at the eye (comp:445-449) reads the RAW leaf words: startIOF looks at properties[0]
+    // without testing alpha, the one place where the refraction byte of an alpha-0 leaf is observable.
+    // One lookup per ray from a wave-uniform position: plain explicit descent over the record array.
+    static VRT_DEV void eye_medium(const KArgs &a, const Ctx &c, I3 p, uint32_t &w0, uint32_t &w1) {
+        w0 = 0u; w1 = 0u;
+        if (!in_world_u(a, p)) return;
+        uint32_t m = c.root.x, b = c.root.y;
+        I3 mn{a.wmin[0], a.wmin[1], a.wmin[2]}, mx{a.wmax[0], a.wmax[1], a.wmax[2]};
+        for (int i = 0; i < 16; ++i) {
+            const int cx = mn.x + ((mx.x - mn.x) >> 1), cy = mn.y + ((mx.y - mn.y) >> 1), cz = mn.z + ((mx.z - mn.z) >> 1);
+            const bool hx = p.x >= cx, hy = p.y >= cy, hz = p.z >= cz;
+            const uint32_t ci = (hx ? 4u : 0u) | (hy ? 2u : 0u) | (hz ? 1u : 0u);
+            mn = I3{hx ? cx : mn.x, hy ? cy : mn.y, hz ? cz : mn.z};
+            mx = I3{hx ? mx.x : cx, hy ? mx.y : cy, hz ? mx.z : cz};
+            const uint32_t bit = 1u << ci;
+            if (!(m & bit)) return;
+            const uint2 rec = a.nodes[b + (uint32_t)__builtin_popcount(m & (bit - 1u))];
+            if (m & (bit << 8)) { w0 = rec.x; w1 = rec.y; return; }
+            m = rec.x; b = rec.y;
+        }
     }
 
     // octreeFind (comp:137-220) for a point known to be inside the world.
@@ -148,26 +178,26 @@ struct Trav {
         return find_node(a, c, p, dpos, w);
     }
 
-    static VRT_DEV void eye_medium(const KArgs &a, const Ctx &c, I3 p, uint32_t &w0, uint32_t &w1) {
-        Walk w;
-        reset(w);
-        Found f = find_checked(a, c, p, I3{0, 0, 0}, w);
-        w0 = f.w0; w1 = f.w1;
-    }
-
     // One DDA step (comp:278-307): leave the current node through its nearest far plane.
-    static VRT_DEV int dda_step(F3 &rp, F3 dir, F3 inv, F3 push, I3 plane) {
+    // The exit axis (comp:292) is kept as two predicates: x = tx<ty && tx<tz, y = !(tx<ty) && ty<tz, else z.
+    // tStep = min(tMax.x, min(tMax.y, tMax.z)) (comp:291) equals the tMax of that axis: where two of them tie
+    // the values are equal, so picking either is the same number.
+    struct Axis { bool x, y; };
+    static VRT_DEV Axis dda_step(F3 &rp, F3 dir, F3 inv, F3 push, I3 plane) {
         const float tx = ((float)plane.x - rp.x) * inv.x;
         const float ty = ((float)plane.y - rp.y) * inv.y;
         const float tz = ((float)plane.z - rp.z) * inv.z;
-        const float t = fmin_c(tx, fmin_c(ty, tz));
-        const int axis = (tx < ty) ? ((tx < tz) ? 0 : 2) : ((ty < tz) ? 1 : 2);
+        const bool xy = tx < ty, xz = tx < tz, yz = ty < tz;
+        const bool ax = xy && xz;
+        const bool ay = !xy && yz;
+        const bool az = !(ax || ay);
+        const float t = ax ? tx : (ay ? ty : tz);
         rp.x = rp.x + dir.x * t; rp.y = rp.y + dir.y * t; rp.z = rp.z + dir.z * t;
         const float qx = rp.x + push.x, qy = rp.y + push.y, qz = rp.z + push.z;
-        rp.x = axis == 0 ? qx : rp.x;
-        rp.y = axis == 1 ? qy : rp.y;
-        rp.z = axis == 2 ? qz : rp.z;
-        return axis;
+        rp.x = ax ? qx : rp.x;
+        rp.y = ay ? qy : rp.y;
+        rp.z = az ? qz : rp.z;
+        return Axis{ax, ay};
     }
 
     // hitMarching (comp:248-330)
@@ -187,25 +217,26 @@ struct Trav {
         reset(w);
         I3 mp = floor_i3_fast(rp);
         Found cur = find_checked(a, c, mp, dpos, w);
-        uint32_t cur_b = medium_byte(cur.w0, cur.w1);
-        int axis = 0;
+        uint32_t cur_b = cur.w1 & 0xffu;  // medium byte: every Found carries 0 here when alpha == 0
+        Axis ax{false, false};
         bool hit = false, go;
         uint32_t pw0 = 0u, pw1 = 0u;
         int i = 0;
         do {
-            axis = dda_step(rp, dir, inv, push, cur.plane);
+            ax = dda_step(rp, dir, inv, push, cur.plane);
             mp = floor_i3_fast(rp);
             const bool inw = in_world_u(a, mp);
             if (inw) {
                 pw0 = cur.w0; pw1 = cur.w1;
                 const uint32_t prev_b = cur_b ? cur_b : iof_byte;
                 cur = find_node(a, c, mp, dpos, w);
-                cur_b = medium_byte(cur.w0, cur.w1);
+                cur_b = cur.w1 & 0xffu;
                 hit = (cur_b ? cur_b : 85u) != prev_b;
             }
             ++i;
             go = inw && !hit && i < 1024;
         } while (go);
+        const int axis = ax.x ? 0 : (ax.y ? 1 : 2);
         const float n = -comp(sd, axis);
         h.axis = axis; h.n = n;
         h.map = mp; h.point = rp; h.p0 = pw0; h.p1 = pw1; h.h0 = cur.w0; h.h1 = cur.w1;

@@ -110,6 +110,15 @@ int child_of(const std::vector<Record> &recs, uint32_t rec, uint32_t ci, uint32_
     return (masks & (bit << 8)) ? kLeaf : kInternal;
 }
 
+// The property word a wide cell carries: refraction byte forced to 0 when the leaf's alpha byte is 0, so
+// that the kernels' medium test (alpha > 0 && refraction > 0, raytracing.comp:318-319) is one AND. The
+// shader overwrites the properties of alpha-0 voxels before reading them (comp:503-504), so the byte is
+// unobservable there; the lookup at the eye, which is not, reads the record array instead.
+inline uint32_t leaf_props(const Record &leaf) {
+    const uint32_t w1 = leaf.w1 & 0x00ffffffu;
+    return (leaf.w0 >> 24) != 0u ? w1 : (w1 & 0x00ffff00u);
+}
+
 bool build_wide_node(const std::vector<Record> &recs, uint32_t rec, int shift, WideTree &out, uint32_t &node, std::string &why) {
     node = out.n_nodes++;
     out.cells.resize((size_t)out.n_nodes * 64, WideCell{0u, 0u});
@@ -124,14 +133,14 @@ bool build_wide_node(const std::vector<Record> &recs, uint32_t rec, int shift, W
             c.w1 = (uint32_t)(shift - 1) << 24;
         } else if (k1 == kLeaf) {
             c.w0 = recs[i1].w0;
-            c.w1 = (recs[i1].w1 & 0x00ffffffu) | ((uint32_t)(shift - 1) << 24);
+            c.w1 = leaf_props(recs[i1]) | ((uint32_t)(shift - 1) << 24);
         } else {
             const int k2 = child_of(recs, i1, lo, i2);
             if (k2 == kAbsent) {
                 c.w1 = (uint32_t)(shift - 2) << 24;
             } else if (k2 == kLeaf) {
                 c.w0 = recs[i2].w0;
-                c.w1 = (recs[i2].w1 & 0x00ffffffu) | ((uint32_t)(shift - 2) << 24);
+                c.w1 = leaf_props(recs[i2]) | ((uint32_t)(shift - 2) << 24);
             } else {
                 if (shift - 2 < 2) {
                     why = "an internal node of unit size lies inside an aligned cube";
@@ -220,7 +229,7 @@ int wide_find_host(const std::vector<Record> &records, const WideTree &wt, const
         uint32_t idx = 0;
         const int kind = child_of(records, rec, ci, idx);
         if (kind == kAbsent) return 0;
-        if (kind == kLeaf) { w0 = records[idx].w0; w1 = records[idx].w1; return 1; }
+        if (kind == kLeaf) { w0 = records[idx].w0; w1 = leaf_props(records[idx]); return 1; }
         rec = idx;
     }
     return 0;

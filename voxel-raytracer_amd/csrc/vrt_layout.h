@@ -51,7 +51,8 @@ bool has_unit_internal_node(const std::vector<Record> &records, const int wmin[3
 // bits of each coordinate (cell = x2 << 4 | y2 << 2 | z2) -- no mask, no popcount, one 8-byte load
 // per TWO octree levels. A cell holds everything octreeFind would return for any point in it:
 //
-//   cell.w0, cell.w1[23:0] : the leaf words (0/0 = empty space)
+//   cell.w0, cell.w1[23:0] : the leaf words (0/0 = empty space); the refraction byte w1[7:0] is stored as 0
+//                            when the alpha byte w0[31:24] is 0 (see leaf_props() in vrt_layout.cpp)
 //   cell.w1[28:24]         : t = log2(side) of the octree node the point falls in (leaf or absent
 //                            child; it may be larger than the cell, then the cell is one of several
 //                            copies), from which the kernel rebuilds that node's AABB
