@@ -106,18 +106,18 @@ int fail(vrt_ctx *c, int code, const std::string &msg) {
             return fail((c), VRT_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-template <int MODE, class TRAV, int TW, int BLOCK, int WPE>
+template <int MODE, class TRAV, int TW, int BLOCK, int WPE, bool PERSIST = false>
 hipError_t launch_one(const vrt::KArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
     if (lds_bytes > 48 * 1024) {  // above the default dynamic-LDS ceiling: opt in (CDNA4 has 160 KiB per CU)
         static bool raised = false;
         if (!raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             if (e != hipSuccess) return e;
             raised = true;
         }
     }
-    hipLaunchKernelGGL((vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE>), dim3(grid), dim3(BLOCK), lds_bytes, s, a);
+    hipLaunchKernelGGL((vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST>), dim3(grid), dim3(BLOCK), lds_bytes, s, a);
     return hipGetLastError();
 }
 
@@ -129,6 +129,11 @@ hipError_t launch_mode(const Variant &v, const vrt::KArgs &a, int grid, size_t l
     using V2 = vrt::v2::Trav<false>;
     using V2L = vrt::v2::Trav<true>;
     using V3 = vrt::v3::Trav;
+    if (v.blocks_per_cu > 0) {  // the persistent (grid-stride) form exists for one combination
+        if (v.trav == 2 && !v.use_lds && v.tw == 8 && v.block == 256 && v.wpe == 1)
+            return launch_one<MODE, V2, 8, 256, 1, true>(a, grid, lds, s);
+        return hipErrorInvalidValue;
+    }
     const int key = v.trav * 1000000 + (v.use_lds ? 100000 : 0) + v.tw * 1000 + (v.block / 64) * 10 + v.wpe;
     switch (key) {
         case 1000000 + 8000 + 40 + 1: return launch_one<MODE, V1, 8, 256, 1>(a, grid, lds, s);
