@@ -80,6 +80,14 @@ int vrt_set_params(vrt_ctx *ctx, const vrt_params *p);
 int vrt_upload_octree(vrt_ctx *ctx, const uint8_t *texels, size_t used_bytes, uint32_t tex_dim);
 int vrt_get_scene_info(const vrt_ctx *ctx, vrt_scene_info *info);
 
+/* EXTENSION (not a reference interface): upload the device record array itself -- 2 x uint32 per record,
+ * level order, root first; internal: {child_mask | leaf_mask << 8, first child index}, leaf:
+ * {R | G<<8 | B<<16 | alpha<<24, refr | illum<<8 | k<<16} -- as vrth_world_records() (vrt_host.h) emits it
+ * straight from the pointer octree. It replaces the reference's full re-flatten + re-upload on every edit
+ * (src/main.cpp:903-914 -> :264-311) and is not limited to 2^23 texels (src/octree.cpp:556-570).
+ * tex_dim must still be ceil(cbrt(_octree_texel_size(tree))): it feeds the voxelID output. */
+int vrt_upload_records(vrt_ctx *ctx, const uint32_t *records, size_t n_records, uint32_t tex_dim);
+
 /* Column-major mat4 x2 + vec4, exactly the std140 Camera block (comp:17-21). */
 int vrt_set_camera(vrt_ctx *ctx, const float inv_projection[16], const float inv_view[16],
                    const float camera_pos[4]);

@@ -45,6 +45,10 @@ size_t vrth_world_texel_count(vrth_world *w); /* _octree_texel_size */
 /* updateGPUTexture's host half (src/main.cpp:264-271): texel stream + tex_dim.
  * *texels is malloc'd (release with vrth_free); empty world -> NULL, 0, dim 1 */
 int vrth_world_flatten(vrth_world *w, uint8_t **texels, size_t *bytes, uint32_t *tex_dim);
+/* EXTENSION: the device record array for vrt_upload_records() (vrt.h) straight from the pointer octree --
+ * no texel stream, no 2^23-texel limit. *records is malloc'd (vrth_free), 2 uint32 per record.
+ * Returns 0, or -2 when the root is itself a leaf (use the texel path then). */
+int vrth_world_records(vrth_world *w, uint32_t **records, size_t *n_records, uint32_t *tex_dim);
 void vrth_free(void *p);
 
 /* Camera(position, up=(0,1,0), yaw, pitch) -> the dispatch's Camera block for a width x height frame;

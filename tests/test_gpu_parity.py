@@ -271,6 +271,54 @@ def test_denoise_pass_matches_quad_frag_restatement(ctx, V, O, product_scenes):
     _assert_same(ctx.denoise(rgba, idd), O.denoise(rgba, idd), "denoise synthetic")
 
 
+def test_record_upload_extension(ctx, V, O, product_scenes):
+    """vrt_upload_records: same pixels as the texel path; and a scene beyond the stream's 2^23-texel limit, which
+    the texel path must refuse, renders identically under the three traversals (no oracle exists for it)."""
+    w = V.World()
+    assert w.load_vox(os.path.join(MAPS, "dragon.vox"))
+    rec, dim = w.records()
+    tex, dim2 = product_scenes["dragon"]
+    W, H = 200, 120
+    ip, iv, cp, _ = V.camera_block((63.5, 60.5, 140.5), -90.0, -10.0, W, H)
+    ctx.set_params(ctx.default_params())
+    ctx.set_camera(ip, iv, cp)
+    ctx.upload_octree(tex, dim2)
+    ref = [ctx.dispatch(W, H, m) for m in (0, 1, 2)]
+    ctx.upload_records(rec, dim)
+    for m in (0, 1, 2):
+        rgba, idd = ctx.dispatch(W, H, m)
+        _assert_same(rgba, ref[m][0], f"records path mode {m} rgba8")
+        _assert_same(idd, ref[m][1], f"records path mode {m} id/dist")
+    with pytest.raises(V.VrtError, match="out of order|two parents"):
+        bad = rec.copy()
+        bad[0, 1] = 0  # root's children would start at the root itself
+        ctx.upload_records(bad, dim)
+    # 176^3 three-dimensional checkerboard: nothing merges, ~9.4 M texels
+    n = 176
+    g = np.indices((n, n, n)).reshape(3, -1).T
+    g = g[(g.sum(axis=1) & 1) == 0].astype(np.int32)
+    big = V.World()
+    big.insert_many(g, np.where((g[:, 0] // 8 + g[:, 2] // 8) & 1, 0xc86432ff, 0x3296c8ff).astype(np.uint32))
+    assert big.texel_count() > 2 ** 23
+    rec, dim = big.records()
+    btex, bdim = big.flatten()
+    with pytest.raises(V.VrtError, match="2\\^23"):
+        ctx.upload_octree(btex, bdim)
+    ctx.upload_records(rec, dim)
+    ip, iv, cp, _ = V.camera_block((300.5, 260.5, 330.5), -130.0, -30.0, W, H)
+    ctx.set_camera(ip, iv, cp)
+    for m in (0, 1):
+        frames = []
+        for v in (0, 1, 4):
+            ctx.set_variant(v)
+            frames.append(ctx.dispatch(W, H, m))
+        assert np.count_nonzero(frames[0][1][..., 0]) > 0.2 * W * H
+        for k in (1, 2):
+            _assert_same(frames[k][0], frames[0][0], f"big scene mode {m} traversal {k} rgba8")
+            _assert_same(frames[k][1], frames[0][1], f"big scene mode {m} traversal {k} id/dist")
+    ctx.set_variant(0)
+
+
 def test_materials_highlight_and_translucent_fallback(ctx, V, O):
     """Emissive, translucent and highlighted voxels + a camera sitting inside a translucent medium."""
     w = V.World()

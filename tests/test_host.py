@@ -297,3 +297,34 @@ def test_wide_layout_other_world_bounds_and_refusals(V, O):
             f = O.lib().o_find_point(C.byref(s2), (C.c_int32 * 3)(*[int(v) for v in p]), leaf, mn, mx)
             w0 = (leaf[0] | leaf[1] << 8 | leaf[2] << 16 | leaf[7] << 24) if f else 0
             assert int(o[0]) == w0 and list(o[2:5].view(np.int32)) == list(mn) and list(o[5:8].view(np.int32)) == list(mx)
+
+
+def test_records_from_tree_equal_records_from_texel_stream(V, product_scenes):
+    """EXTENSION path: the record array emitted straight from the pointer octree is the one the uploader derives
+    from octree_texture()'s stream -- on the shipped maps and on random edit sequences."""
+    import os
+    for name in ("dragon", "monu9", "nature"):
+        w = V.World()
+        assert w.load_vox(os.path.join(MAPS, name + ".vox"))
+        rec_tree, dim_tree = w.records()
+        tex, dim = product_scenes[name]
+        rec_tex, info = V.build_layout(tex)
+        assert dim_tree == dim and np.array_equal(rec_tree, rec_tex), name
+    rng = np.random.default_rng(12)
+    w = V.World()
+    xyz, rgba = random_voxels(rng, 5000, -200, 300)
+    w.insert_many(xyz, rgba)
+    for i in rng.permutation(5000)[:1500]:
+        w.remove(*[int(v) for v in xyz[i]])
+    w.insert_many(xyz[:700], np.full(700, 0x224466ff, np.uint32))
+    tex, dim = w.flatten()
+    rec_tree, dim_tree = w.records()
+    assert dim_tree == dim and np.array_equal(rec_tree, V.build_layout(tex)[0])
+    # an empty world and a world merged into a single root leaf
+    e = V.World()
+    rec, d = e.records()
+    assert d == 1 and np.array_equal(rec, V.build_layout(np.zeros(0, np.uint8))[0]) and rec[0, 0] == 0
+    s = V.World(world_min=(0, 0, 0), world_max=(4, 4, 4))
+    pts = np.array([(x, y, z) for x in range(4) for y in range(4) for z in range(4)], np.int32)
+    s.insert_many(pts, np.full(len(pts), 0x102030ff, np.uint32))
+    assert s.records() is None

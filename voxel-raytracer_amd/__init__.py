@@ -213,6 +213,21 @@ class World:
         host_lib().vrth_free(p)
         return arr, int(d.value)
 
+    def records(self):
+        """EXTENSION: the device record array straight from the tree -> (uint32[n,2], tex_dim), or None when the
+        root is itself a leaf (texel path only)."""
+        L = host_lib()
+        L.vrth_world_records.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]
+        p, n, d = C.c_void_p(), C.c_size_t(0), C.c_uint32(0)
+        r = L.vrth_world_records(self._h, C.byref(p), C.byref(n), C.byref(d))
+        if r == -2:
+            return None
+        if r != 0:
+            raise VrtError("vrth_world_records failed")
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n.value, 2)).copy()
+        L.vrth_free(p)
+        return arr, int(d.value)
+
     def fill_terrain(self, size=1024, seed=1337):
         if host_lib().vrth_world_fill_terrain(self._h, size, seed) != 0:
             raise VrtError("vrth_world_fill_terrain failed")
@@ -314,6 +329,12 @@ class Context:
     def upload_octree(self, texels, tex_dim):
         t = np.ascontiguousarray(texels, np.uint8)
         self._chk(self._L.vrt_upload_octree(self._h, t.ctypes.data if t.size else None, t.size, tex_dim))
+
+    def upload_records(self, records, tex_dim):
+        """EXTENSION: upload the record array World.records() returns (no texel stream, no 2^23-texel limit)."""
+        r = np.ascontiguousarray(records, np.uint32).reshape(-1, 2)
+        self._L.vrt_upload_records.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]
+        self._chk(self._L.vrt_upload_records(self._h, r.ctypes.data, r.shape[0], tex_dim))
 
     def scene_info(self):
         info = SceneInfo()

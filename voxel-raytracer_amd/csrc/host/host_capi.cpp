@@ -153,6 +153,62 @@ int vrth_world_flatten(vrth_world *w, uint8_t **texels, size_t *bytes, uint32_t 
     return 0;
 }
 
+// The device record array (level order, 2 words per record; layout in voxel-raytracer_amd/csrc/vrt_layout.h)
+// emitted straight from the pointer octree: what vrt_upload_octree() would derive from octree_texture()'s
+// stream, without writing or re-parsing that stream. Same presence rule (a child counts when it holds a
+// voxel or has children), same leaf bytes ((u8)(refraction*85), (u8)(illumination*255), (u8)(k*255)), same
+// 16-level cut-off. Returns -2 for a tree whose root is itself a leaf (the stream form of that tree is
+// read by the shader as a header; use the texel path for it).
+int vrth_world_records(vrth_world *w, uint32_t **records, size_t *n_records, uint32_t *tex_dim) {
+    if (!w || !records || !n_records || !tex_dim) return -1;
+    Octree *root = w->root;
+    const size_t texels = _octree_texel_size(root);
+    size_t d = (size_t)ceil(cbrt((double)texels));
+    *tex_dim = (uint32_t)(d == 0 ? 1 : d);
+    if (!root->children && root->has_voxel) return -2;
+    struct Item { const Octree *n; uint32_t rec, depth; };
+    std::vector<uint32_t> out(2, 0u);
+    std::vector<Item> queue;
+    queue.push_back(Item{root, 0u, 0u});
+    for (size_t head = 0; head < queue.size(); ++head) {
+        const Item it = queue[head];
+        uint32_t mask = 0, leaf_mask = 0;
+        if (it.n->children && it.depth < 15)
+            for (int i = 0; i < 8; ++i) {
+                const Octree *c = it.n->children[i];
+                if (c && (c->has_voxel || c->children)) mask |= 1u << i;
+            }
+        const uint32_t first = (uint32_t)(out.size() / 2);
+        for (int i = 0; i < 8; ++i) {
+            if (!(mask & (1u << i))) continue;
+            const Octree *c = it.n->children[i];
+            const uint32_t idx = (uint32_t)(out.size() / 2);
+            if (!c->children && c->has_voxel) {
+                const ColorRGBA col = c->voxel.color;
+                const uint32_t w0 = (uint32_t)get_red_rgba(col) | ((uint32_t)get_green_rgba(col) << 8) |
+                                    ((uint32_t)get_blue_rgba(col) << 16) | ((uint32_t)get_alpha_rgba(col) << 24);
+                const uint32_t w1 = (uint32_t)(uint8_t)(c->voxel.voxel.refraction * 85.0f) |
+                                    ((uint32_t)(uint8_t)(c->voxel.voxel.illumination * 255.0f) << 8) |
+                                    ((uint32_t)(uint8_t)(c->voxel.voxel.k * 255.0f) << 16);
+                out.push_back(w0);
+                out.push_back(w1);
+                leaf_mask |= 1u << i;
+            } else {
+                out.push_back(0u);
+                out.push_back(0u);
+                queue.push_back(Item{c, idx, it.depth + 1});
+            }
+        }
+        out[2 * (size_t)it.rec] = mask | (leaf_mask << 8);
+        out[2 * (size_t)it.rec + 1] = first;
+    }
+    *n_records = out.size() / 2;
+    *records = (uint32_t *)malloc(out.size() * sizeof(uint32_t));
+    if (!*records) return -1;
+    memcpy(*records, out.data(), out.size() * sizeof(uint32_t));
+    return 0;
+}
+
 void vrth_free(void *p) { free(p); }
 
 int vrth_camera_block(const float pos[3], float yaw, float pitch, int width, int height, float inv_projection[16],

@@ -381,6 +381,65 @@ int vrt_upload_octree(vrt_ctx *c, const uint8_t *texels, size_t used_bytes, uint
     return VRT_OK;
 }
 
+// Extension beyond the reference boundary: take the device record array (vrt_layout.h) directly, as
+// libvrt_host.so emits it from the pointer octree (vrth_world_records). Skips the texel stream, and with
+// it the stream's 23-bit pointer limit and the flatten + re-parse on every edit.
+int vrt_upload_records(vrt_ctx *c, const uint32_t *records, size_t n_records, uint32_t tex_dim) {
+    if (!c) return VRT_E_INVALID;
+    if (!records || n_records == 0 || n_records > (1ull << 31)) return fail(c, VRT_E_INVALID, "vrt_upload_records: bad record array");
+    if (tex_dim == 0) tex_dim = 1;
+    // structural check: every child index lies after its parent (level order) and inside the array, so a
+    // descent always terminates; depth is bounded by the same 16-iteration rule as the texel path
+    std::vector<vrt::Record> recs(n_records);
+    std::memcpy(recs.data(), records, n_records * sizeof(vrt::Record));
+    std::vector<uint8_t> kind(n_records, 0);  // 1 internal, 2 leaf
+    std::vector<uint8_t> depth(n_records, 0);
+    kind[0] = 1;
+    uint32_t n_internal = 0, n_leaves = 0, max_depth = 0;
+    for (size_t i = 0; i < n_records; ++i) {
+        if (kind[i] != 1) { if (kind[i] == 2) ++n_leaves; continue; }
+        ++n_internal;
+        uint32_t mask = recs[i].w0 & 0xffu;
+        const uint32_t leaf_mask = (recs[i].w0 >> 8) & 0xffu, base = recs[i].w1;
+        if (depth[i] >= 15) { recs[i].w0 = 0; mask = 0; }
+        const uint32_t n_child = (uint32_t)__builtin_popcount(mask);
+        if (n_child == 0) continue;
+        if (base <= i || (size_t)base + n_child > n_records) return fail(c, VRT_E_MALFORMED, "vrt_upload_records: child index out of order or range");
+        uint32_t rank = 0;
+        for (uint32_t ci = 0; ci < 8; ++ci) {
+            if (!((mask >> ci) & 1u)) continue;
+            const size_t idx = (size_t)base + rank++;
+            if (kind[idx] != 0) return fail(c, VRT_E_MALFORMED, "vrt_upload_records: a record has two parents");
+            kind[idx] = ((leaf_mask >> ci) & 1u) ? 2 : 1;
+            depth[idx] = (uint8_t)(depth[i] + 1);
+            if (depth[idx] > max_depth) max_depth = depth[idx];
+        }
+    }
+    VRT_HIP(c, hipSetDevice(c->device));
+    const size_t bytes = n_records * sizeof(vrt::Record);
+    if (bytes > c->nodes_capacity) {
+        VRT_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->d_nodes) VRT_HIP(c, hipFree(c->d_nodes));
+        c->d_nodes = nullptr;
+        c->nodes_capacity = 0;
+        VRT_HIP(c, hipMalloc((void **)&c->d_nodes, bytes));
+        c->nodes_capacity = bytes;
+    }
+    VRT_HIP(c, hipMemcpyAsync(c->d_nodes, recs.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    VRT_HIP(c, hipStreamSynchronize(c->stream));
+    c->info.tex_dim = tex_dim;
+    c->info.n_texels = 0;
+    c->info.n_records = (uint32_t)n_records;
+    c->info.n_internal = n_internal;
+    c->info.n_leaves = n_leaves;
+    c->info.max_depth = max_depth;
+    c->info.lds_records = 0;
+    c->host_records.swap(recs);
+    c->analysis_valid = false;
+    c->have_scene = true;
+    return VRT_OK;
+}
+
 int vrt_get_scene_info(const vrt_ctx *c, vrt_scene_info *info) {
     if (!c || !info) return VRT_E_INVALID;
     *info = c->info;
