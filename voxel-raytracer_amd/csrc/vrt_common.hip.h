@@ -80,6 +80,11 @@ struct Hit {
     float n;          // -sign(rayDir[axis]): +1, -1, or -0 for a zero direction component
     uint32_t p0, p1;  // prevVoxel leaf words
     uint32_t h0, h1;  // hitVoxel leaf words
+    // where the traversal stood when the march ended (meaning private to the TRAV policy): lets the shadow
+    // ray, which starts 2e-3 off the hit point, begin its first lookup there instead of at the root
+    uint32_t r_node, r_anode;
+    int r_s, r_as;
+    I3 r_last;
 };
 
 // exp() convention shared with the oracle (Cephes-style, plain mul/add)
@@ -230,7 +235,7 @@ VRT_DEV void trace_pixel(const KArgs &a, const typename TRAV::Ctx &tc_, const fl
                 for (int k = 0; k < 3; ++k) fc[k] = fc[k] + tc[k] * sc[k] * emission * 1.0f;
             } else {
                 int lit = 1;
-                if (MODE == 1) lit = TRAV::shadow(a, tc_, add3(h.point, scale3(normal, 2e-3f)), light);
+                if (MODE == 1) lit = TRAV::shadow(a, tc_, add3(h.point, scale3(normal, 2e-3f)), light, h);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     float direct = a.global_light[k] * (float)lit * ndotl;

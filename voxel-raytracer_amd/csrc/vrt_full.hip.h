@@ -277,7 +277,7 @@ __device__ void trace_pixel_full(const KArgs &a, const typename TRAV::Ctx &tc_, 
                 continue;
             }
             if (r.depth == 0) {
-                const int lit = TRAV::shadow(a, tc_, add3(hp, scale3(normal, 2e-3f)), light);
+                const int lit = TRAV::shadow(a, tc_, add3(hp, scale3(normal, 2e-3f)), light, h);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const float direct = gl[k] * (float)lit * ndotl;

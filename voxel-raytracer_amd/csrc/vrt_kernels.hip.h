@@ -1,4 +1,5 @@
-// vrt_kernels.hip.h -- traversal variant "v2" (the default): bit-indexed descent.
+// vrt_kernels.hip.h -- traversal variant "v2": bit-indexed descent over the record array. The fallback
+// when a scene has no wide form (vrt_kernels_wide.hip.h, the default), and the middle rung of the A/B ladder.
 //
 // The PMC profile of v1 (profiles/r01_a_pmc_summary_v1_variant1.txt) shows the
 // path is instruction-issue bound on gfx950 (99.7 % L1 hits, ~4300 VALU
@@ -237,7 +238,7 @@ struct Trav {
     }
 
     // notInShadow (comp:333-377); the light direction is used as given
-    static VRT_DEV int shadow(const KArgs &a, const Ctx &c, F3 origin, F3 ld) {
+    static VRT_DEV int shadow(const KArgs &a, const Ctx &c, F3 origin, F3 ld, const Hit & /*resume hint unused*/) {
         F3 rp = origin, inv;
         inv.x = (__builtin_fabsf(ld.x) < 1e-8f) ? 1e20f : 1.0f / ld.x;
         inv.y = (__builtin_fabsf(ld.y) < 1e-8f) ? 1e20f : 1.0f / ld.y;

@@ -134,7 +134,7 @@ struct Trav {
     }
 
     // notInShadow (comp:333-377); the light direction is used as given
-    static VRT_DEV int shadow(const KArgs &a, const Ctx &c, F3 origin, F3 ld) {
+    static VRT_DEV int shadow(const KArgs &a, const Ctx &c, F3 origin, F3 ld, const Hit & /*resume hint unused*/) {
         F3 rp = origin, inv;
         inv.x = (__builtin_fabsf(ld.x) < 1e-8f) ? 1e20f : 1.0f / ld.x;
         inv.y = (__builtin_fabsf(ld.y) < 1e-8f) ? 1e20f : 1.0f / ld.y;

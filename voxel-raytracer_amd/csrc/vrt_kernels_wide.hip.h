@@ -240,11 +240,12 @@ struct Trav {
         const float n = -comp(sd, axis);
         h.axis = axis; h.n = n;
         h.map = mp; h.point = rp; h.p0 = pw0; h.p1 = pw1; h.h0 = cur.w0; h.h1 = cur.w1;
+        h.r_node = w.node; h.r_s = w.s; h.r_anode = w.anode; h.r_as = w.as; h.r_last = w.last;
         return hit;
     }
 
     // notInShadow (comp:333-377); the light direction is used as given
-    static VRT_DEV int shadow(const KArgs &a, const Ctx &c, F3 origin, F3 ld) {
+    static VRT_DEV int shadow(const KArgs &a, const Ctx &c, F3 origin, F3 ld, const Hit &h) {
         F3 rp = origin, inv;
         inv.x = (__builtin_fabsf(ld.x) < 1e-8f) ? 1e20f : 1.0f / ld.x;
         inv.y = (__builtin_fabsf(ld.y) < 1e-8f) ? 1e20f : 1.0f / ld.y;
@@ -252,8 +253,8 @@ struct Trav {
         const I3 dpos{ld.x > 0.0f ? 1 : 0, ld.y > 0.0f ? 1 : 0, ld.z > 0.0f ? 1 : 0};
         const F3 push{sign_c(ld.x) * 0.001f, sign_c(ld.y) * 0.001f, sign_c(ld.z) * 0.001f};
         I3 mp = floor_i3_fast(rp);
-        Walk w;
-        reset(w);
+        Walk w;  // resume where the primary ray stopped: the origin is 2e-3 off its hit point
+        w.node = h.r_node; w.s = h.r_s; w.anode = h.r_anode; w.as = h.r_as; w.last = h.r_last;
         Found v = find_checked(a, c, mp, dpos, w);
         int lit = 1, i = 0;
         bool go;
