@@ -153,19 +153,17 @@ def main():
     ctx.set_camera(ip, iv, cp)
 
     plan = shd.ShardPlan(W, H, args.tile_rows, rank, world)
-    local = plan.local_buffer(dev)
-    p_rgba, p_id = plan.pointers(local)
-    gathered = plan.gather_buffer(dev) if (rank == 0 and world > 1) else None
-    store = plan.frame_store(dev) if rank == 0 else None
-    index = plan.scatter_index(dev) if rank == 0 else None
+    # double-buffered frames: the gather of frame i (RCCL, its own stream) overlaps the trace of frame i+1
+    pipe = shd.FramePipeline(plan, dev, stage_through_host=via_host)
     stream = torch.cuda.current_stream(dev).cuda_stream  # launch on torch's stream so the gather orders after it
 
     def step():
+        k, p_rgba, p_id = pipe.slot()
         ctx.dispatch_shard(W, H, args.tile_rows, rank, world, mode, p_rgba, p_id, stream)
-        if world > 1:
-            shd.gather_frame(plan, local, gathered, store, index, stage_through_host=via_host)
+        pipe.submit(k)
 
     def fence():
+        pipe.drain()  # every frame submitted so far is gathered and assembled on rank 0
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -188,9 +186,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # frame assembled once more outside the timed region for the self-check (N=1 path has no gather in step())
-    if world == 1:
-        shd.gather_frame(plan, local, None, store, index)
     torch.cuda.synchronize(dev)
 
     if rank == 0:
@@ -198,7 +193,7 @@ def main():
         key = {"dragon": "dragon_1080p", "monu9": "monu9_720p", "nature": "nature_4k"}.get(args.map, "-") + f"/mode{mode}"
         g = frames.get(key)
         known = g is not None and (g["width"], g["height"]) == (W, H)
-        frame_rgba, frame_id = plan.frame_views(store)
+        frame_rgba, frame_id = pipe.frame_views()
         rgba_host = frame_rgba.cpu().numpy().view("uint8").reshape(H, W, 4)
         id_host = frame_id.cpu().numpy()
         check = None
@@ -241,7 +236,8 @@ def main():
             "data": (f"tests/golden/maps/{args.map}.vox scene fixture" if args.map != "terrain" else
                      "procedural 1024x1024 heightfield (vrth_world_fill_terrain, seed 1337)") + ", fixed synthetic camera pose",
             "config": {"workload": f"{args.map}.vox {W}x{H} {args.mode} rays, pose {pose}", "mode": args.mode,
-                       "sharding": f"interleaved {args.tile_rows}-row tiles over {world} rank(s), gather to rank 0 in-step",
+                       "sharding": f"interleaved {args.tile_rows}-row tiles over {world} rank(s); every frame gathered to rank 0 "
+                                   "inside the timed region, double-buffered (gather of frame i overlaps trace of frame i+1)",
                        "variant": args.variant, "collective_backend": args.backend if world > 1 else None},
             "roofline": roofline,
             "pixels_match_oracle_golden": check,

@@ -85,3 +85,69 @@ def gather_frame(plan, local, gathered, store, index, group=None, stage_through_
     if plan.rank != 0:
         return
     store.index_copy_(0, index, src.view(plan.world * 3 * plan.rows_max, plan.width))
+
+
+class FramePipeline:
+    """Double-buffered frames: the gather of frame i overlaps the tracing of frame i+1.
+
+    A synchronous gather makes the compute stream wait for the collective, so a step costs trace + gather.
+    Here every rank owns two shard buffers (rank 0 also two receive tensors); frame i is traced into buffer
+    i % 2 and its gather is issued asynchronously (RCCL runs it on its own stream behind an event); the
+    only waits are the ones data hazards need: before buffer i % 2 is overwritten by frame i + 2, gather i
+    must have completed -- at that point rank 0 also scatters frame i into the frame store. A step then
+    costs max(trace, gather) once the pipe is full. drain() completes the frames still in flight.
+    """
+
+    def __init__(self, plan, device, group=None, stage_through_host=False):
+        self.plan, self.group, self.via_host = plan, group, stage_through_host
+        self.local = [plan.local_buffer(device) for _ in range(2)]
+        root = plan.rank == 0
+        self.gathered = [plan.gather_buffer(device) if (root and plan.world > 1) else None for _ in range(2)]
+        self.store = plan.frame_store(device) if root else None
+        self.index = plan.scatter_index(device) if root else None
+        self.pending = [None, None]   # per slot: None | "sync" | async work handle
+        self.frame = 0
+
+    def slot(self):
+        """(slot index, rgba pointer, id pointer) of the buffer the NEXT frame must be traced into; makes that
+        buffer safe to overwrite first."""
+        k = self.frame % 2
+        self._retire(k)
+        p_rgba, p_id = self.plan.pointers(self.local[k])
+        return k, p_rgba, p_id
+
+    def submit(self, k):
+        """call after the trace of the frame in slot k has been enqueued on the current stream"""
+        plan = self.plan
+        if plan.world == 1:
+            self.pending[k] = "sync"
+        elif self.via_host and self.local[k].is_cuda:
+            gather_frame(plan, self.local[k], self.gathered[k], self.store, self.index, self.group, True)
+            self.pending[k] = None
+        else:
+            recv = list(self.gathered[k].unbind(0)) if plan.rank == 0 else None
+            self.pending[k] = dist.gather(self.local[k], recv, dst=0, group=self.group, async_op=True)
+        self.frame += 1
+
+    def _retire(self, k, final=False):
+        h = self.pending[k]
+        if h is None:
+            return
+        plan = self.plan
+        self.pending[k] = None
+        if plan.world == 1:
+            # one GPU: the compact buffer IS the frame (rows in order); it is only copied into the store on drain
+            if final:
+                self.store.index_copy_(0, self.index, self.local[k].view(3 * plan.rows_max, plan.width))
+            return
+        h.wait()
+        if plan.rank == 0:
+            self.store.index_copy_(0, self.index, self.gathered[k].view(plan.world * 3 * plan.rows_max, plan.width))
+
+    def drain(self):
+        """completes the (up to two) frames still in flight, oldest first"""
+        for k in ((self.frame % 2), ((self.frame + 1) % 2)):
+            self._retire(k, final=True)
+
+    def frame_views(self):
+        return self.plan.frame_views(self.store)
