@@ -49,6 +49,8 @@ int vrth_world_flatten(vrth_world *w, uint8_t **texels, size_t *bytes, uint32_t 
  * no texel stream, no 2^23-texel limit. *records is malloc'd (vrth_free), 2 uint32 per record.
  * Returns 0, or -2 when the root is itself a leaf (use the texel path then). */
 int vrth_world_records(vrth_world *w, uint32_t **records, size_t *n_records, uint32_t *tex_dim);
+/* the same for a caller that holds the Octree* itself (octree.hpp) */
+int vrth_octree_records(void *octree_root, uint32_t **records, size_t *n_records, uint32_t *tex_dim);
 void vrth_free(void *p);
 
 /* Camera(position, up=(0,1,0), yaw, pitch) -> the dispatch's Camera block for a width x height frame;

@@ -160,8 +160,14 @@ int vrth_world_flatten(vrth_world *w, uint8_t **texels, size_t *bytes, uint32_t 
 // 16-level cut-off. Returns -2 for a tree whose root is itself a leaf (the stream form of that tree is
 // read by the shader as a header; use the texel path for it).
 int vrth_world_records(vrth_world *w, uint32_t **records, size_t *n_records, uint32_t *tex_dim) {
-    if (!w || !records || !n_records || !tex_dim) return -1;
-    Octree *root = w->root;
+    if (!w) return -1;
+    return vrth_octree_records(w->root, records, n_records, tex_dim);
+}
+
+// the same for a C++ caller that holds the Octree* itself (the reference's chunk0)
+int vrth_octree_records(void *octree_root, uint32_t **records, size_t *n_records, uint32_t *tex_dim) {
+    if (!octree_root || !records || !n_records || !tex_dim) return -1;
+    Octree *root = static_cast<Octree *>(octree_root);
     const size_t texels = _octree_texel_size(root);
     size_t d = (size_t)ceil(cbrt((double)texels));
     *tex_dim = (uint32_t)(d == 0 ? 1 : d);
