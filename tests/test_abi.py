@@ -51,6 +51,20 @@ def test_no_gpu_means_loud_failure_not_fallback(V):
     assert "no CPU path" in str(e.value) or "HIP" in str(e.value)
 
 
+def test_cpp_example_links_against_kept_api_and_fails_loudly_without_gpu(V):
+    """examples/frame_main.cpp uses the reference's own names (octree_create, load_vox_file, Camera, ...) and the
+    C-ABI; it must build from include/ + the two libraries, and with no GPU exit non-zero with a message."""
+    import subprocess
+    import torch
+    exe = os.path.join(ROOT, "examples", "frame_main")
+    assert os.path.exists(exe), "make -C voxel-raytracer_amd/csrc builds it"
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([exe, os.path.join(ROOT, "tests/golden/maps/monu9.vox"), "32", "16"], capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 2 and r.stderr.strip(), (r.returncode, r.stderr)
+
+
 def test_argument_validation_without_device(V):
     L = V.hip_lib()
     assert L.vrt_create(0, None) == -1

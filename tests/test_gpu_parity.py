@@ -419,3 +419,37 @@ def test_error_behaviour(V):
     with pytest.raises(V.VrtError, match="record limit"):
         c.upload_octree(cyc, 3)
     c.close()
+
+
+def test_cpp_frame_loop_example_matches_oracle(V, O):
+    """examples/frame_main.cpp is the reference's frame loop (load, flatten, upload, pick ray, edit, re-upload,
+    full-shader dispatch, display pass) written against include/ the way src/main.cpp is written against the
+    reference's headers; its three per-frame hashes must be the oracle's for the same sequence."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "examples", "frame_main")
+    assert os.path.exists(exe), "examples/frame_main was not built (make -C voxel-raytracer_amd/csrc)"
+    W, H = 192, 108
+    r = subprocess.run([exe, os.path.join(MAPS, "dragon.vox"), str(W), str(H)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("frame ")]
+    assert len(lines) == 2
+    w = V.World()
+    assert w.load_vox(os.path.join(MAPS, "dragon.vox"))
+    pos = (63.5, 60.5, 140.5)
+    ip, iv, cp, front = V.camera_block(pos, -90.0, -10.0, W, H)
+    for f, ln in enumerate(lines):
+        hit = w.ray_cast(pos, front)
+        hl = hit[0] if hit and hit[1] else (-1, -1, -1)
+        if f == 1 and hit and hit[1]:
+            w.remove(*hit[0])
+            w.insert(60, 70, 40, 0xffd2d2ff, 3.0, 1.0, 0.0)
+        tex, dim = w.flatten()
+        rgba, idd, _ = _oracle_frame(O, tex, dim, (ip, iv, cp), W, H, 2, highlighted=hl)
+        shown = O.denoise(rgba, idd)
+        want = {"tex_dim": str(dim), "rgba": "%016x" % V.fnv1a64(rgba), "id": "%016x" % V.fnv1a64(idd),
+                "shown": "%016x" % V.fnv1a64(shown)}
+        got = {k: ln[ln.index(k) + 1] for k in want}
+        assert [int(v) for v in ln[ln.index("highlighted") + 1: ln.index("highlighted") + 4]] == list(hl), (f, ln, hl)
+        for k, v in want.items():
+            assert got[k] == v, (f, k, got[k], v)
