@@ -256,8 +256,10 @@ def test_denoise_pass_matches_quad_frag_restatement(ctx, V, O, product_scenes):
         _setup(ctx, V, tex, dim, pose, W, H)
         rgba, idd = ctx.dispatch(W, H, 2)
         ref = O.denoise(rgba, idd)
-        got = ctx.denoise(rgba, idd)
-        _assert_same(got, ref, f"denoise {name} {W}x{H}")
+        for dv in (1, 0):                                                          # one, two pixels per lane
+            ctx.set_denoise_variant(dv)
+            got = ctx.denoise(rgba, idd)
+            _assert_same(got, ref, f"denoise {name} {W}x{H} kernel {dv}")
         assert np.array_equal(got[idd[..., 0] == 0], rgba[idd[..., 0] == 0])      # sky passes through
         if name == "dragon":
             assert np.any(got != rgba)                                             # and it did blur something
@@ -268,7 +270,23 @@ def test_denoise_pass_matches_quad_frag_restatement(ctx, V, O, product_scenes):
     idd = np.zeros((H, W, 2), np.int32)
     idd[..., 0] = rng.integers(-3, 4, size=(H, W))
     idd[..., 1] = rng.choice([0, 1, 2, 50, 99, 100, 101, 400, 2047, 40000], size=(H, W))
-    _assert_same(ctx.denoise(rgba, idd), O.denoise(rgba, idd), "denoise synthetic")
+    ref = O.denoise(rgba, idd)
+    for dv in (1, 0):
+        ctx.set_denoise_variant(dv)
+        _assert_same(ctx.denoise(rgba, idd), ref, f"denoise synthetic kernel {dv}")
+    # radii that differ by one or by many inside a wave, image sizes off the 32 x 16 tile, one object id everywhere
+    for (W, H) in [(67, 35), (130, 50)]:
+        rgba = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8)
+        idd = np.zeros((H, W, 2), np.int32)
+        idd[..., 0] = 7
+        idd[H // 3, W // 2, 0] = 0
+        yy, xx = np.mgrid[0:H, 0:W]
+        for dist in (100 + (xx + yy) // 3, 100 + 60 * ((xx // 5 + yy // 3) % 4), 90 + (xx * 37 + yy * 11) % 400):
+            idd[..., 1] = dist
+            ref = O.denoise(rgba, idd)
+            for dv in (1, 0):
+                ctx.set_denoise_variant(dv)
+                _assert_same(ctx.denoise(rgba, idd), ref, f"denoise radii {W}x{H} kernel {dv}")
 
 
 def test_record_upload_extension(ctx, V, O, product_scenes):

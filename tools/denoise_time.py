@@ -1,0 +1,58 @@
+"""Times the display pass (quad.frag restatement) on device buffers: python tools/denoise_time.py [map] [W H]."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vrt_import  # noqa: E402
+
+V = vrt_import.vrt()
+import torch  # noqa: E402
+
+POSES = {"dragon": (63.5, 60.5, 140.5, -90.0, -10.0), "monu9": (48.5, 60.5, 170.5, -90.0, -12.0),
+         "nature": (60.5, 80.5, 330.5, -90.0, -12.0)}
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "dragon"
+    W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    w = V.World()
+    assert w.load_vox(os.path.join(root, "tests/golden/maps", name + ".vox"))
+    tex, dim = w.flatten()
+    ctx = V.Context(0)
+    ctx.upload_octree(tex, dim)
+    pose = POSES[name]
+    ip, iv, cp, _ = V.camera_block(pose[:3], pose[3], pose[4], W, H)
+    ctx.set_camera(ip, iv, cp)
+    ctx.set_params(ctx.default_params())
+    rgba, idd = ctx.dispatch(W, H, 2)
+    if os.environ.get("DENOISE_SYNTH"):        # every pixel summed with one radius: DENOISE_SYNTH=<dist>
+        idd[..., 0] = 5
+        idd[..., 1] = int(os.environ["DENOISE_SYNTH"])
+    d_rgba = torch.from_numpy(rgba.view(np.int32).reshape(H, W)).cuda()
+    d_id = torch.from_numpy(idd).cuda()
+    outs = []
+    for variant in (1, 0):
+        ctx.set_denoise_variant(variant)
+        d_out = torch.zeros_like(d_rgba)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()      # a null stream handle would select the context's own stream
+        stream = side.cuda_stream
+        for _ in range(int(os.environ.get("DENOISE_ITERS", 300))):   # default: long enough for the clocks to settle
+            ctx.denoise_device(W, H, d_rgba.data_ptr(), d_id.data_ptr(), d_out.data_ptr(), stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = int(os.environ.get("DENOISE_ITERS", 100))
+        e0.record(side)
+        for _ in range(n):
+            ctx.denoise_device(W, H, d_rgba.data_ptr(), d_id.data_ptr(), d_out.data_ptr(), stream)
+        e1.record(side)
+        torch.cuda.synchronize()
+        outs.append(d_out.cpu().numpy())
+        print("denoise variant %d  %s %dx%d  %.4f ms" % (variant, name, W, H, e0.elapsed_time(e1) / n))
+    print("variants agree:", all(bool(np.array_equal(outs[0], o)) for o in outs[1:]))
+
+
+if __name__ == "__main__":
+    main()

@@ -2,7 +2,7 @@
 # Collects rocprofv3 PMC counters for bench.py in separate passes (kernel-trace/--stats are never combined
 # with --pmc here). Usage (on the GPU box): tools/pmc.sh <out_dir> [bench args...]
 set -u
-OUT=$1; shift
+OUT=$(realpath -m "$1"); shift
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp

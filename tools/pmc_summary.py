@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Averages rocprofv3 --pmc counter CSVs per kernel: tools/pmc_summary.py <dir with pass*/ sub-dirs>."""
+"""Averages rocprofv3 --pmc counter CSVs per kernel: tools/pmc_summary.py <dir with pass*/ sub-dirs> [kernel name substring]."""
 import csv
 import glob
 import os
@@ -9,11 +9,12 @@ from collections import defaultdict
 
 def main():
     root = sys.argv[1]
+    want = sys.argv[2] if len(sys.argv) > 2 else "trace_kernel"
     acc = defaultdict(lambda: defaultdict(list))
     for path in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(path)):
             k = row.get("Kernel_Name", "?")
-            if "trace_kernel" not in k:
+            if want not in k:
                 continue
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, ctrs in acc.items():

@@ -122,6 +122,7 @@ def hip_lib():
         L.vrt_synchronize.argtypes = [C.c_void_p]
         L.vrt_denoise.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vrt_denoise_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vrt_debug_set_denoise_variant.argtypes = [C.c_void_p, C.c_int]
         L.vrt_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.vrt_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
         L.vrt_stream.restype = C.c_void_p
@@ -401,6 +402,10 @@ class Context:
 
     def denoise_device(self, width, height, d_rgba, d_id, d_out, stream=None):
         self._chk(self._L.vrt_denoise(self._h, width, height, d_rgba, d_id, d_out, stream))
+
+    def set_denoise_variant(self, v):
+        """Pixels per lane of the display-pass kernel: 0 = two (default), 1 = one."""
+        self._chk(self._L.vrt_debug_set_denoise_variant(self._h, v))
 
     def synchronize(self):
         self._chk(self._L.vrt_synchronize(self._h))

@@ -70,6 +70,7 @@ struct vrt_ctx {
     vrt_params params{};
     float inv_proj[16]{}, inv_view[16]{}, cam_pos[4]{};
     int variant = 0;
+    int denoise_variant = 0;  // pixels per lane: 0 -> two, 1 -> one (vrt_debug_set_denoise_variant)
     // scratch outputs for the host-buffer dispatch
     void *d_rgba = nullptr;
     void *d_id = nullptr;
@@ -555,10 +556,16 @@ int vrt_denoise(vrt_ctx *c, int width, int height, const void *d_rgba8, const vo
     a.out = (uint32_t *)d_out_rgba8;
     a.width = width;
     a.height = height;
-    const dim3 grid((unsigned)((width + vrt::denoise::kTile - 1) / vrt::denoise::kTile),
-                    (unsigned)((height + vrt::denoise::kTile - 1) / vrt::denoise::kTile));
-    hipLaunchKernelGGL(vrt::denoise::denoise_kernel, grid, dim3(vrt::denoise::kTile, vrt::denoise::kTile), 0,
-                       stream ? (hipStream_t)stream : c->stream, a);
+    const hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (c->denoise_variant == 1) {
+        const dim3 grid((unsigned)((width + vrt::denoise::kTile - 1) / vrt::denoise::kTile),
+                        (unsigned)((height + vrt::denoise::kTile - 1) / vrt::denoise::kTile));
+        hipLaunchKernelGGL(vrt::denoise::denoise_kernel, grid, dim3(vrt::denoise::kTile, vrt::denoise::kTile), 0, s, a);
+    } else {
+        using namespace vrt::denoise;
+        const dim3 grid((unsigned)((width + kTW - 1) / kTW), (unsigned)((height + 15) / 16));
+        hipLaunchKernelGGL((denoise_px_kernel<2, 16>), grid, dim3(kTW / 2, 16), 0, s, a);
+    }
     VRT_HIP(c, hipGetLastError());
     return VRT_OK;
 }
@@ -627,6 +634,12 @@ void *vrt_stream(vrt_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int vrt_device(const vrt_ctx *c) { return c ? c->device : VRT_E_INVALID; }
 
 // Arithmetic-contract probe (see math_probe_kernel): host arrays in/out, synchronous.
+int vrt_debug_set_denoise_variant(vrt_ctx *c, int v) {
+    if (!c || v < 0 || v > 1) return VRT_E_INVALID;
+    c->denoise_variant = v;
+    return VRT_OK;
+}
+
 int vrt_debug_math(vrt_ctx *c, int op, const float *x, const float *y, float *out, int n) {
     if (!c || !x || !y || !out || n < 1) return VRT_E_INVALID;
     VRT_HIP(c, hipSetDevice(c->device));

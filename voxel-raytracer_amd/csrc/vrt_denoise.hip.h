@@ -82,5 +82,267 @@ __global__ __launch_bounds__(kTile *kTile) void denoise_kernel(const Args a) {
     a.out[p] = unorm8(s0 / d) | (unorm8(s1 / d) << 8) | (unorm8(s2 / d) << 16) | (255u << 24);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// PX pixels per lane. The one-pixel kernel above reads 16 LDS bytes per tap per pixel and is bound by
+// LDS bandwidth and by waiting on it. Here a lane owns PX horizontally adjacent pixels and walks the
+// UNION of their windows, x = -R .. R+PX-1 relative to its first pixel: one ds_read_b128 ({r, g, b, id})
+// serves up to PX windows, and every pixel still receives its own taps in the shader's order (y outer,
+// x inner), so each fp32 sum rounds as before.
+//   * the add is an fma with a 0/1 mask (s = fma(m, c, s)): adding +0 leaves a non-negative sum
+//     unchanged, so the masked form is bit-identical to the shader's conditional add; (r,g) and
+//     (b,count) go through packed fp32 fma: compare, select, two v_pk_fma_f32 per tap and pixel;
+//   * taps outside the image are staged with id 0 and can never equal a summed pixel's id (pixels
+//     with id 0 pass through), which reproduces quad.frag's bounds test (:60-63) without clipping
+//     the loops;
+//   * rows are straight-line code specialised on the wave's largest radius RM and on the spread DELTA of
+//     its radii (rows_static): compile-time LDS offsets, no scalar address arithmetic, reads hoisted
+//     ahead of use; only the DELTA taps at either end of a pixel's span take a per-pixel range test.
+//     DELTA 0 (one radius; the common case, R moves slowly across the image) and 1 have their own
+//     instances, any larger spread runs the instance that tests every tap.
+// Tile 32 x 16 pixels (+20 halo = 72 x 56 taps, 70 KB LDS with the padded row stride, two workgroups per CU).
+// Within a row the tap columns are stored column-mod-PX major (position = (col % PX) * (72 / PX) + col / PX) so
+// that the lanes of a row, which read columns PX apart, hit consecutive 16-byte slots.
+// The shipped instance is PX = 2: 16 x 16 lanes = four waves per workgroup, one per SIMD, so two resident
+// workgroups always put two waves on every SIMD. PX = 4 halves the LDS reads and needs 4.25 instead of 4.5
+// vector instructions per tap and pixel, but its two-wave workgroups land on SIMDs at the dispatcher's whim and
+// measured 30% slower on rendered frames. Measured on MI355X (tools/denoise_time.py, 1080p dragon / 4K nature /
+// every pixel summed at radius 20): 0.34 / 0.18 / 0.49 ms against 0.68 / 0.53 / 1.76 ms for the one-pixel kernel.
+// What bounds it: v_pk_fma_f32 issues in ~6 cycles, not 4 (tools/micro/valu_rate.hip), which puts a tap-and-pixel
+// at ~21 cycles of one SIMD; the dense frame runs within 10% of that, rendered frames lose the rest to the spread
+// of per-tile work (sky tiles are free, radius-20 tiles take ~50 us a wave).
+constexpr int kTW = 32;                  // tile width; the height TH is a kernel parameter (16 by default)
+constexpr int kSpanX = kTW + 2 * kMaxR;  // 72
+constexpr int kFull = kMaxR;             // DELTA value of the instance that range-tests every tap
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int PX>
+struct Acc {
+    f2 rg[PX];
+    f2 bc[PX];  // (blue sum, tap count)
+};
+
+// LDS row stride in 16-byte slots. ds_read_b128 is served 16 lanes at a time, lanes {0-3,12-15,20-27} first
+// (MI355X guide, LDS table): with 16 lanes per pixel row (PX = 2) that group spans two rows and is conflict-free
+// only when the row stride is a multiple of 256 B; with 8 lanes per row (PX = 4) it spans four rows and the
+// natural 72-slot stride (1152 B = 128 mod 256) already spreads them over all banks.
+template <int PX>
+constexpr int kStride = PX == 2 ? 80 : kSpanX;
+
+template <int PX>
+__device__ __forceinline__ int slot(const int col) {
+    return (col % PX) * (kSpanX / PX) + col / PX;
+}
+
+__device__ __forceinline__ void tap(const f4 rec, const int cid, f2 &rg, f2 &bc, const bool in_range = true) {
+    const float m = (__float_as_int(rec.w) == cid && in_range) ? 1.0f : 0.0f;
+    const f2 mm = {m, m};
+    const f2 c01 = {rec.x, rec.y};
+    const f2 c2 = {rec.z, 1.0f};
+    rg = __builtin_elementwise_fma(mm, c01, rg);
+    bc = __builtin_elementwise_fma(mm, c2, bc);
+}
+
+// RM is the largest radius among the wave's summed pixels, DELTA (wave-uniform) at least RM - the smallest.
+// Tap u of a row (x = u - RM relative to pixel 0) can only matter to pixel k when k <= u <= k + 2RM, and it
+// lies in EVERY pixel's window, whatever that pixel's own radius, when k + DELTA <= u <= k + 2RM - DELTA and
+// the row is one of the middle 2(RM-DELTA)+1: those taps need no test. Pixel k takes any other tap when
+// |u - RM - k| <= R[k] and |y| <= R[k].
+// `row` is the lane's first window row (y = -RM) at the lane's column base. Each row is straight-line code; the
+// compiler hoists the row's LDS reads ahead of their use. (Cutting the row into register double-buffered chunks
+// pinned by empty asm statements was measured: 4% faster on a frame where every wave has one radius, 10-25% slower
+// on rendered frames, so the rows are left to the scheduler.)
+template <int PX, int RM, int DELTA>
+__device__ __forceinline__ void rows_static(const f4 *row, const int (&cid)[PX], const int (&R)[PX], Acc<PX> &acc) {
+    constexpr int D = DELTA < RM ? DELTA : RM;
+    unsigned extent[PX];
+    int inner_first[PX];
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+        extent[k] = (unsigned)(2 * R[k]);
+        inner_first[k] = RM - R[k] + k;
+    }
+#pragma unroll 1
+    for (int y = -RM; y <= RM; ++y, row += kStride<PX>) {
+        const bool middle = D == 0 || (D < RM && y >= -(RM - D) && y <= RM - D);  // wave-uniform
+        if (middle) {
+#pragma unroll
+            for (int u = 0; u < 2 * RM + PX; ++u) {
+                const f4 t = row[slot<PX>(kMaxR - RM + u)];
+#pragma unroll
+                for (int k = 0; k < PX; ++k) {
+                    if (u < k || u > k + 2 * RM) continue;
+                    if (u >= k + D && u <= k + 2 * RM - D)
+                        tap(t, cid[k], acc.rg[k], acc.bc[k]);
+                    else
+                        tap(t, cid[k], acc.rg[k], acc.bc[k], (unsigned)(u - inner_first[k]) <= extent[k]);
+                }
+            }
+        } else {
+            int first[PX];  // a row outside pixel k's window gets a lower bound no tap reaches
+#pragma unroll
+            for (int k = 0; k < PX; ++k) first[k] = (y >= -R[k] && y <= R[k]) ? inner_first[k] : 4 * kMaxR;
+#pragma unroll
+            for (int u = 0; u < 2 * RM + PX; ++u) {
+                const f4 t = row[slot<PX>(kMaxR - RM + u)];
+#pragma unroll
+                for (int k = 0; k < PX; ++k) {
+                    if (u < k || u > k + 2 * RM) continue;
+                    tap(t, cid[k], acc.rg[k], acc.bc[k], (unsigned)(u - first[k]) <= extent[k]);
+                }
+            }
+        }
+    }
+}
+
+template <int PX, int DELTA>
+__device__ __forceinline__ void rows_dispatch(const f4 *row, const int rm, const int (&cid)[PX], const int (&R)[PX], Acc<PX> &acc) {
+    switch (rm) {
+#define VRT_DENOISE_CASE(r) \
+    case r:                 \
+        rows_static<PX, r, DELTA>(row, cid, R, acc); \
+        break;
+        VRT_DENOISE_CASE(1) VRT_DENOISE_CASE(2) VRT_DENOISE_CASE(3) VRT_DENOISE_CASE(4) VRT_DENOISE_CASE(5)
+        VRT_DENOISE_CASE(6) VRT_DENOISE_CASE(7) VRT_DENOISE_CASE(8) VRT_DENOISE_CASE(9) VRT_DENOISE_CASE(10)
+        VRT_DENOISE_CASE(11) VRT_DENOISE_CASE(12) VRT_DENOISE_CASE(13) VRT_DENOISE_CASE(14) VRT_DENOISE_CASE(15)
+        VRT_DENOISE_CASE(16) VRT_DENOISE_CASE(17) VRT_DENOISE_CASE(18) VRT_DENOISE_CASE(19) VRT_DENOISE_CASE(20)
+#undef VRT_DENOISE_CASE
+    }
+}
+
+// One tile (bx, by) by one workgroup of (32 / PX) x TH lanes; s_unorm holds byte / 255.0f. Ends with every lane
+// past its last LDS read of this tile, but not synchronised.
+template <int PX, int TH>
+__device__ __forceinline__ void tile(const Args &a, const int bx, const int by, f4 *s_rec, const float *s_unorm) {
+    constexpr int kTH = TH, kSpanY = TH + 2 * kMaxR;
+    constexpr int kLanesX = kTW / PX, kThreads = kLanesX * kTH, kTaps = kSpanX * kSpanY;
+    static_assert(kSpanX % PX == 0, "column swizzle");
+    const int tid = threadIdx.y * kLanesX + threadIdx.x;
+    const int px0 = bx * kTW + threadIdx.x * PX, py = by * kTH + threadIdx.y;
+    int cid[PX], R[PX];
+    int r_hi = 0, r_lo = kMaxR + 1;
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+        const int px = px0 + k;
+        cid[k] = 0;
+        R[k] = 1;
+        if (px < a.width && py < a.height) {
+            const int2 center = a.id[(size_t)py * (size_t)a.width + (size_t)px];
+            cid[k] = center.x;
+            const float radius_f = 200.0f / __builtin_sqrtf((float)(center.y > 1 ? center.y : 1));  // quad.frag:45
+            const int r = (int)radius_f;
+            R[k] = r < 1 ? 1 : (r > kMaxR ? kMaxR : r);                                           // :48
+        }
+        if (cid[k] != 0) {
+            r_hi = R[k] > r_hi ? R[k] : r_hi;
+            r_lo = R[k] < r_lo ? R[k] : r_lo;
+        }
+    }
+    // a tile of sky (quad.frag:36-39 for every pixel) copies its colours and never stages a window
+    if (!__syncthreads_or(r_hi)) {
+        if (py < a.height) {
+#pragma unroll
+            for (int k = 0; k < PX; ++k)
+                if (px0 + k < a.width) {
+                    const size_t p = (size_t)py * (size_t)a.width + (size_t)(px0 + k);
+                    a.out[p] = a.rgba[p];
+                }
+        }
+        return;
+    }
+    // stage the 72 x (TH + 40) window: loads of a whole batch are issued before the first is consumed
+    const int tx0 = bx * kTW - kMaxR, ty0 = by * kTH - kMaxR;
+    constexpr int kBatch = 8;
+    constexpr int kStageIters = (kTaps + kThreads * kBatch - 1) / (kThreads * kBatch) * kBatch;
+    for (int b = 0; b < kStageIters; b += kBatch) {
+        int vid[kBatch];
+        uint32_t col[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int i = tid + (b + j) * kThreads;
+            const int lx = i % kSpanX, ly = i / kSpanX;
+            const int gx = tx0 + lx, gy = ty0 + ly;
+            vid[j] = 0;
+            col[j] = 0u;
+            if (i < kTaps && gx >= 0 && gx < a.width && gy >= 0 && gy < a.height) {
+                const size_t g = (size_t)gy * (size_t)a.width + (size_t)gx;
+                vid[j] = a.id[g].x;
+                col[j] = a.rgba[g];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int i = tid + (b + j) * kThreads;
+            const int lx = i % kSpanX, ly = i / kSpanX;
+            f4 rec;
+            rec.x = s_unorm[col[j] & 0xffu];
+            rec.y = s_unorm[(col[j] >> 8) & 0xffu];
+            rec.z = s_unorm[(col[j] >> 16) & 0xffu];
+            rec.w = __int_as_float(vid[j]);
+            if (i < kTaps) s_rec[ly * kStride<PX> + slot<PX>(lx)] = rec;
+        }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int h = __shfl_xor(r_hi, off), l = __shfl_xor(r_lo, off);
+        r_hi = h > r_hi ? h : r_hi;
+        r_lo = l < r_lo ? l : r_lo;
+    }
+    r_hi = __builtin_amdgcn_readfirstlane(r_hi);
+    r_lo = __builtin_amdgcn_readfirstlane(r_lo);
+
+    Acc<PX> acc;
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+        acc.rg[k] = f2{0.0f, 0.0f};
+        acc.bc[k] = f2{0.0f, 0.0f};
+    }
+    if (r_hi != 0) {  // some pixel of this wave is summed
+        const int rm = r_hi, delta = r_hi - r_lo;
+        const f4 *row = s_rec + (threadIdx.y + kMaxR - rm) * kStride<PX> + threadIdx.x;  // window row -rm, lane column base
+        if (delta == 0)
+            rows_dispatch<PX, 0>(row, rm, cid, R, acc);
+        else if (delta == 1)
+            rows_dispatch<PX, 1>(row, rm, cid, R, acc);
+        else
+            rows_dispatch<PX, kFull>(row, rm, cid, R, acc);
+    }
+    if (py >= a.height) return;
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+        const int px = px0 + k;
+        if (px >= a.width) break;
+        const size_t p = (size_t)py * (size_t)a.width + (size_t)px;
+        if (cid[k] == 0) {  // quad.frag:36-39
+            a.out[p] = a.rgba[p];
+            continue;
+        }
+        const float d = fmax_c(acc.bc[k].y, 1.0f);
+        a.out[p] = unorm8(acc.rg[k].x / d) | (unorm8(acc.rg[k].y / d) << 8) | (unorm8(acc.bc[k].x / d) << 16) | (255u << 24);
+    }
+}
+
+
+template <int PX, int TH>
+__device__ __forceinline__ void fill_unorm(float *s_unorm) {
+    for (int i = threadIdx.y * (kTW / PX) + threadIdx.x; i < 256; i += kTW / PX * TH) s_unorm[i] = (float)i / 255.0f;
+    __syncthreads();
+}
+
+// One workgroup per tile. waves_per_eu(2, 2) keeps an instance within 256 registers: the default kernel (PX = 2,
+// TH = 16: four waves per workgroup, two workgroups per CU by LDS) needs two waves to share a SIMD. Without it the
+// compiler, seeing occupancy already limited by LDS, spreads into AGPRs and the second workgroup no longer fits.
+template <int PX, int TH>
+__global__ __launch_bounds__(kTW / PX *TH) __attribute__((amdgpu_waves_per_eu(2, 2))) void denoise_px_kernel(const Args a) {
+    __shared__ f4 s_rec[kStride<PX> * (TH + 2 * kMaxR)];
+    __shared__ float s_unorm[256];
+    fill_unorm<PX, TH>(s_unorm);
+    tile<PX, TH>(a, blockIdx.x, blockIdx.y, s_rec, s_unorm);
+}
+
 }  // namespace denoise
 }  // namespace vrt
