@@ -471,3 +471,80 @@ def test_cpp_frame_loop_example_matches_oracle(V, O):
         assert [int(v) for v in ln[ln.index("highlighted") + 1: ln.index("highlighted") + 4]] == list(hl), (f, ln, hl)
         for k, v in want.items():
             assert got[k] == v, (f, k, got[k], v)
+
+
+def test_seeded_random_scenes_uniforms_and_cameras(ctx, V, O):
+    """A bounded random sweep: worlds of random clusters and slabs with random materials, random uniforms
+    (globalLight, lightDir, voxelScale, highlighted voxel), random poses inside and outside the model, odd frame
+    sizes; all three modes against the oracle, bit for bit."""
+    rng = np.random.default_rng(20251)
+    palette = [(0xa0a0a0ff, 3.0, 0.0, 0.0), (0x50b43cff, 3.0, 0.0, 0.0), (0xffd2d2ff, 3.0, 1.0, 0.0),
+               (0x3c64dc96, 1.33, 0.0, 0.02), (0xc8dcff50, 1.5, 0.0, 0.0), (0xff3030ff, 3.0, 0.25, 0.0),
+               (0x20202000, 1.2, 0.0, 0.0)]
+    frames_with_hits = hit_pixels = 0
+    for case in range(10):
+        w = V.World()
+        span = int(rng.choice([12, 40, 200]))
+        pts = []
+        for _ in range(int(rng.integers(1, 5))):                       # slabs
+            y = int(rng.integers(0, span // 2 + 1))
+            x0, z0 = (int(v) for v in rng.integers(-span // 4, span // 2, size=2))
+            sx, sz = (int(v) for v in rng.integers(2, 14, size=2))
+            m = palette[int(rng.integers(0, len(palette)))]
+            xs, zs = np.meshgrid(np.arange(x0, x0 + sx), np.arange(z0, z0 + sz))
+            xyz = np.stack([xs.ravel(), np.full(xs.size, y), zs.ravel()], axis=1)
+            w.insert_many(xyz, np.full(len(xyz), m[0], np.uint32), m[1], m[2], m[3])
+            pts.append(xyz)
+        for _ in range(int(rng.integers(3, 9))):                       # clusters
+            c = rng.integers(-span // 4, span, size=3)
+            n = int(rng.integers(1, 60))
+            xyz = (c + rng.integers(-3, 4, size=(n, 3))).astype(np.int32)
+            m = palette[int(rng.integers(0, len(palette)))]
+            w.insert_many(xyz, np.full(n, m[0], np.uint32), m[1], m[2], m[3])
+            pts.append(xyz)
+        pts = np.concatenate(pts)
+        tex, dim = w.flatten()
+        ctx.upload_octree(tex, dim)
+        for _ in range(2):
+            W, H = int(rng.integers(9, 90)), int(rng.integers(7, 60))
+            target = pts[int(rng.integers(0, len(pts)))] + 0.5           # look at a voxel that exists
+            away = rng.normal(size=3)
+            away[1] = abs(away[1]) + 0.2
+            pos = target + away / np.linalg.norm(away) * rng.choice([1.7, 6.0, span * 0.5, span * 1.5])
+            d = target - pos
+            yaw = float(np.degrees(np.arctan2(d[2], d[0])))
+            pitch = float(np.clip(np.degrees(np.arctan2(d[1], np.hypot(d[0], d[2]))), -89.0, 89.0))
+            ip, iv, cp, _ = V.camera_block(tuple(float(v) for v in pos), yaw, pitch, W, H)
+            ctx.set_camera(ip, iv, cp)
+            p = ctx.default_params()
+            s = O.make_scene(tex, dim, ip, iv, cp)
+            if rng.random() < 0.5:
+                gl = rng.uniform(0.0, 1.5, size=4).astype(np.float32)
+                p.global_light[:] = [float(v) for v in gl]
+                s.global_light[:] = [float(v) for v in gl]
+            if rng.random() < 0.5:
+                ld = rng.normal(size=3)
+                ld = (ld / np.linalg.norm(ld)).astype(np.float32)
+                p.light_dir[:] = [float(v) for v in ld]
+                s.light_dir[:] = [float(v) for v in ld]
+            if rng.random() < 0.3:
+                vs = float(np.float32(rng.choice([0.5, 2.0, 1.25])))
+                p.voxel_scale = vs
+                s.voxel_scale = vs
+            if rng.random() < 0.5:
+                hl = [int(v) for v in rng.integers(-2, span // 2, size=3)]
+                p.highlighted[:] = hl
+                s.highlighted[:] = hl
+            ctx.set_params(p)
+            for mode in (0, 1, 2):
+                ref_rgba, ref_id, _, _ = O.render(s, W, H, mode)
+                rgba, idd = ctx.dispatch(W, H, mode)
+                what = f"random case {case} {W}x{H} pos {np.round(pos, 2)} mode {mode}"
+                _assert_same(rgba, ref_rgba, what + " rgba8")
+                _assert_same(idd, ref_id, what + " id/dist")
+                _assert_same(ctx.denoise(rgba, idd), O.denoise(rgba, idd), what + " display pass")
+            n_hit = int(np.count_nonzero(ref_id[..., 0]))
+            frames_with_hits += n_hit > 0
+            hit_pixels += n_hit
+    ctx.set_params(ctx.default_params())
+    assert frames_with_hits >= 15 and hit_pixels > 5000, (frames_with_hits, hit_pixels)   # the sweep looked at geometry
