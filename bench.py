@@ -103,6 +103,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket each launch with hipEvents (roofline is then omitted); for measuring their cost")
+    ap.add_argument("--gather", default="final", choices=["final", "frame"],
+                    help="final: traced frames stay sharded in their ranks' HBM (as a one-GPU run keeps them resident); the "
+                         "last frame is gathered to rank 0 and assembled inside the timed region. frame: EVERY frame is "
+                         "gathered to rank 0 (double-buffered) -- bounded by 12 B/pixel into one GPU's xGMI links")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured path); gloo only rehearses the N>1 code path on a "
                          "box whose ranks share one GPU (collective staged through host memory)")
@@ -153,8 +157,7 @@ def main():
     ctx.set_camera(ip, iv, cp)
 
     plan = shd.ShardPlan(W, H, args.tile_rows, rank, world)
-    # double-buffered frames: the gather of frame i (RCCL, its own stream) overlaps the trace of frame i+1
-    pipe = shd.FramePipeline(plan, dev, stage_through_host=via_host)
+    pipe = shd.FramePipeline(plan, dev, stage_through_host=via_host, gather=args.gather)
     stream = torch.cuda.current_stream(dev).cuda_stream  # launch on torch's stream so the gather orders after it
 
     def step():
@@ -163,7 +166,7 @@ def main():
         pipe.submit(k)
 
     def fence():
-        pipe.drain()  # every frame submitted so far is gathered and assembled on rank 0
+        pipe.drain()  # the newest frame (--gather frame: every frame) is gathered to rank 0 and assembled there
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -236,8 +239,12 @@ def main():
             "data": (f"tests/golden/maps/{args.map}.vox scene fixture" if args.map != "terrain" else
                      "procedural 1024x1024 heightfield (vrth_world_fill_terrain, seed 1337)") + ", fixed synthetic camera pose",
             "config": {"workload": f"{args.map}.vox {W}x{H} {args.mode} rays, pose {pose}", "mode": args.mode,
-                       "sharding": f"interleaved {args.tile_rows}-row tiles over {world} rank(s); every frame gathered to rank 0 "
-                                   "inside the timed region, double-buffered (gather of frame i overlaps trace of frame i+1)",
+                       "sharding": f"interleaved {args.tile_rows}-row tiles over {world} rank(s); " + (
+                           "frames stay sharded in HBM, no collective per step; the last frame is gathered to rank 0 and "
+                           "assembled inside the timed region" if args.gather == "final" else
+                           "every frame gathered to rank 0 inside the timed region, double-buffered (gather of frame i "
+                           "overlaps trace of frame i+1)"),
+                       "gather": args.gather,
                        "variant": args.variant, "collective_backend": args.backend if world > 1 else None},
             "roofline": roofline,
             "pixels_match_oracle_golden": check,

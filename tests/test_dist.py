@@ -43,22 +43,27 @@ WORKER = textwrap.dedent("""
             frame_rgba, frame_id = plan.frame_views(store)
             assert np.array_equal(frame_rgba.numpy().view(np.uint8).reshape(H, W, 4), full_rgba)
             assert np.array_equal(frame_id.numpy(), full_id)
-        # the double-buffered pipeline bench.py uses: 5 frames in flight two at a time, async gathers
-        pipe = shd.FramePipeline(plan, "cpu")
-        for f in range(5):
-            k, _, _ = pipe.slot()
-            buf = pipe.local[k]
-            buf.zero_()
-            if rows:
-                rm = plan.rows_max
-                buf[: rm * W].view(rm, W)[: len(rows)] = torch.from_numpy(full_rgba[rows].copy().view(np.int32).reshape(len(rows), W)) + f
-                buf[rm * W:].view(rm, W, 2)[: len(rows)] = torch.from_numpy(full_id[rows].copy()) - f
-            pipe.submit(k)
-        pipe.drain()
-        if rank == 0:
-            fr, fi = pipe.frame_views()
-            assert np.array_equal(fr.numpy(), full_rgba.view(np.int32).reshape(H, W) + 4)
-            assert np.array_equal(fi.numpy(), full_id - 4)
+        # the pipelines bench.py uses: 5 frames through two buffers; "frame" gathers each one asynchronously,
+        # "final" keeps them sharded and gathers the last one on drain
+        for mode in ("frame", "final"):
+            pipe = shd.FramePipeline(plan, "cpu", gather=mode)
+            for f in range(5):
+                k, _, _ = pipe.slot()
+                buf = pipe.local[k]
+                buf.zero_()
+                if rows:
+                    rm = plan.rows_max
+                    buf[: rm * W].view(rm, W)[: len(rows)] = torch.from_numpy(full_rgba[rows].copy().view(np.int32).reshape(len(rows), W)) + f
+                    buf[rm * W:].view(rm, W, 2)[: len(rows)] = torch.from_numpy(full_id[rows].copy()) - f
+                pipe.submit(k)
+                if f == 1:
+                    pipe.drain()          # a fence in mid-stream (bench.py has one after warm-up)
+            pipe.drain()
+            pipe.drain()                  # idempotent
+            if rank == 0:
+                fr, fi = pipe.frame_views()
+                assert np.array_equal(fr.numpy(), full_rgba.view(np.int32).reshape(H, W) + 4), mode
+                assert np.array_equal(fi.numpy(), full_id - 4), mode
     dist.barrier()
     dist.destroy_process_group()
     sys.stdout.write("rank %d ok\\n" % rank); sys.stdout.flush()

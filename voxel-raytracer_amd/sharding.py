@@ -88,24 +88,33 @@ def gather_frame(plan, local, gathered, store, index, group=None, stage_through_
 
 
 class FramePipeline:
-    """Double-buffered frames: the gather of frame i overlaps the tracing of frame i+1.
+    """Two shard buffers per rank; frame i is traced into buffer i % 2.
 
-    A synchronous gather makes the compute stream wait for the collective, so a step costs trace + gather.
-    Here every rank owns two shard buffers (rank 0 also two receive tensors); frame i is traced into buffer
-    i % 2 and its gather is issued asynchronously (RCCL runs it on its own stream behind an event); the
-    only waits are the ones data hazards need: before buffer i % 2 is overwritten by frame i + 2, gather i
-    must have completed -- at that point rank 0 also scatters frame i into the frame store. A step then
-    costs max(trace, gather) once the pipe is full. drain() completes the frames still in flight.
+    gather="final" (default): frames stay where they were traced -- rank r keeps rows_of[r] of every frame
+    resident in its HBM, exactly as the one-GPU run keeps whole frames resident -- and only drain() moves data:
+    it gathers the LAST frame to rank 0 and assembles it there. The per-pixel path has no exchange step, so the
+    steady state has no collective at all; a consumer of the sharded frames (a sharded display pass, an encoder
+    per rank) reads them in place.
+
+    gather="frame": every frame is delivered to rank 0 (what a single display GPU needs). The gather of frame i
+    is issued asynchronously (RCCL runs it on its own stream behind an event) and overlaps the trace of frame
+    i + 1; the only waits are the ones data hazards need: before buffer i % 2 is overwritten by frame i + 2,
+    gather i must have completed -- at that point rank 0 also scatters frame i into the frame store. A step then
+    costs max(trace, gather) once the pipe is full. 12 B/pixel into ONE GPU bounds this mode: at 1080p that is
+    21.8 MB x (N-1)/N per frame through rank 0's xGMI links.
     """
 
-    def __init__(self, plan, device, group=None, stage_through_host=False):
-        self.plan, self.group, self.via_host = plan, group, stage_through_host
+    def __init__(self, plan, device, group=None, stage_through_host=False, gather="final"):
+        if gather not in ("final", "frame"):
+            raise ValueError("gather must be 'final' or 'frame'")
+        self.plan, self.group, self.via_host, self.mode = plan, group, stage_through_host, gather
         self.local = [plan.local_buffer(device) for _ in range(2)]
         root = plan.rank == 0
-        self.gathered = [plan.gather_buffer(device) if (root and plan.world > 1) else None for _ in range(2)]
+        n_recv = 2 if gather == "frame" else 1
+        self.gathered = [plan.gather_buffer(device) if (root and plan.world > 1) else None for _ in range(n_recv)]
         self.store = plan.frame_store(device) if root else None
         self.index = plan.scatter_index(device) if root else None
-        self.pending = [None, None]   # per slot: None | "sync" | async work handle
+        self.pending = [None, None]   # per slot: None | "resident" | async work handle
         self.frame = 0
 
     def slot(self):
@@ -119,8 +128,8 @@ class FramePipeline:
     def submit(self, k):
         """call after the trace of the frame in slot k has been enqueued on the current stream"""
         plan = self.plan
-        if plan.world == 1:
-            self.pending[k] = "sync"
+        if plan.world == 1 or self.mode == "final":
+            self.pending[k] = "resident"
         elif self.via_host and self.local[k].is_cuda:
             gather_frame(plan, self.local[k], self.gathered[k], self.store, self.index, self.group, True)
             self.pending[k] = None
@@ -135,19 +144,21 @@ class FramePipeline:
             return
         plan = self.plan
         self.pending[k] = None
-        if plan.world == 1:
-            # one GPU: the compact buffer IS the frame (rows in order); it is only copied into the store on drain
+        if h == "resident":
+            # the frame stays in its shard buffer(s); only the last one is assembled on rank 0, on drain
             if final:
-                self.store.index_copy_(0, self.index, self.local[k].view(3 * plan.rows_max, plan.width))
+                gather_frame(plan, self.local[k], self.gathered[0], self.store, self.index, self.group,
+                             self.via_host)
             return
         h.wait()
         if plan.rank == 0:
             self.store.index_copy_(0, self.index, self.gathered[k].view(plan.world * 3 * plan.rows_max, plan.width))
 
     def drain(self):
-        """completes the (up to two) frames still in flight, oldest first"""
-        for k in ((self.frame % 2), ((self.frame + 1) % 2)):
-            self._retire(k, final=True)
+        """completes the frames still in flight, oldest first; afterwards rank 0's store holds the newest frame"""
+        newest = (self.frame + 1) % 2
+        for k in ((self.frame % 2), newest):
+            self._retire(k, final=(k == newest) or self.mode == "frame")
 
     def frame_views(self):
         return self.plan.frame_views(self.store)
