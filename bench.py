@@ -107,6 +107,10 @@ def main():
                     help="final: traced frames stay sharded in their ranks' HBM (as a one-GPU run keeps them resident); the "
                          "last frame is gathered to rank 0 and assembled inside the timed region. frame: EVERY frame is "
                          "gathered to rank 0 (double-buffered) -- bounded by 12 B/pixel into one GPU's xGMI links")
+    ap.add_argument("--streams", type=int, default=0, choices=[0, 1, 2],
+                    help="HIP streams the frames alternate between (2: the drain of one launch overlaps the start of the "
+                         "next). 0 = 1 at one GPU, where the per-launch duration feeds the roofline and must not be "
+                         "inflated by a neighbour, and 2 with more ranks, where a launch is a fraction of a frame")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured path); gloo only rehearses the N>1 code path on a "
                          "box whose ranks share one GPU (collective staged through host memory)")
@@ -157,12 +161,13 @@ def main():
     ctx.set_camera(ip, iv, cp)
 
     plan = shd.ShardPlan(W, H, args.tile_rows, rank, world)
-    pipe = shd.FramePipeline(plan, dev, stage_through_host=via_host, gather=args.gather)
-    stream = torch.cuda.current_stream(dev).cuda_stream  # launch on torch's stream so the gather orders after it
+    n_streams = args.streams or (1 if world == 1 else 2)
+    pipe = shd.FramePipeline(plan, dev, stage_through_host=via_host, gather=args.gather, streams=n_streams)
 
     def step():
         k, p_rgba, p_id = pipe.slot()
-        ctx.dispatch_shard(W, H, args.tile_rows, rank, world, mode, p_rgba, p_id, stream)
+        # on torch-owned streams, so a gather (and the final assembly) orders itself after the trace
+        ctx.dispatch_shard(W, H, args.tile_rows, rank, world, mode, p_rgba, p_id, pipe.stream_handle(k))
         pipe.submit(k)
 
     def fence():
@@ -190,6 +195,27 @@ def main():
         elapsed = float(t.item())
 
     torch.cuda.synchronize(dev)
+
+    # one GPU, informational: the same K frames alternating between two streams (no per-launch events; the figure the
+    # headline would become if overlapped launches were allowed to blur the per-kernel duration the roofline uses)
+    overlapped = None
+    if world == 1 and n_streams == 1:
+        pipe2 = shd.FramePipeline(plan, dev, gather=args.gather, streams=2)
+        for it in range(args.warmup + args.steps):
+            if it == args.warmup:
+                pipe2.drain()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+            k, p_rgba, p_id = pipe2.slot()
+            ctx.dispatch_shard(W, H, args.tile_rows, rank, world, mode, p_rgba, p_id, pipe2.stream_handle(k))
+            pipe2.submit(k)
+        pipe2.drain()
+        torch.cuda.synchronize(dev)
+        e2 = time.perf_counter() - t0
+        f2_rgba, f2_id = pipe2.frame_views()
+        same = bool(torch.equal(f2_rgba, pipe.frame_views()[0]) and torch.equal(f2_id, pipe.frame_views()[1]))
+        overlapped = {"streams": 2, "value": round(W * H * args.steps / e2 / 1e6, 2), "unit": "Mrays/s",
+                      "ms_per_step": round(e2 / args.steps * 1e3, 5), "same_pixels": same}
 
     if rank == 0:
         frames = json.load(open(os.path.join(ROOT, "tests", "golden", "frames.json")))["frames"]
@@ -244,10 +270,11 @@ def main():
                            "assembled inside the timed region" if args.gather == "final" else
                            "every frame gathered to rank 0 inside the timed region, double-buffered (gather of frame i "
                            "overlaps trace of frame i+1)"),
-                       "gather": args.gather,
+                       "gather": args.gather, "streams": n_streams,
                        "variant": args.variant, "collective_backend": args.backend if world > 1 else None},
             "roofline": roofline,
             "pixels_match_oracle_golden": check,
+            "overlapped_frames": overlapped,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, tex, dim, (ip, iv, cp))
