@@ -84,8 +84,12 @@ int main(int argc, char **argv) {
         camera.FillDispatchBlock(screenWidth, screenHeight, invProj, invView, camPos);
         vrt_set_camera(g_vrt, invProj, invView, camPos);
         vrt_set_params(g_vrt, &prm);
-        if (vrt_dispatch(g_vrt, screenWidth, screenHeight, VRT_MODE_FULL, rgba.data(), idDist.data()) != VRT_OK ||
-            vrt_denoise_host(g_vrt, screenWidth, screenHeight, rgba.data(), idDist.data(), shown.data()) != VRT_OK) {
+        // :941-946 dispatch + :951-967 display pass; frame 0 through the two separate calls, frame 1 through the fused one
+        const int rc = frame == 0
+            ? (vrt_dispatch(g_vrt, screenWidth, screenHeight, VRT_MODE_FULL, rgba.data(), idDist.data()) != VRT_OK
+                   ? -1 : vrt_denoise_host(g_vrt, screenWidth, screenHeight, rgba.data(), idDist.data(), shown.data()))
+            : vrt_dispatch_frame(g_vrt, screenWidth, screenHeight, VRT_MODE_FULL, shown.data(), rgba.data(), idDist.data());
+        if (rc != VRT_OK) {
             std::cerr << vrt_last_error(g_vrt) << std::endl;
             return 4;
         }

@@ -129,6 +129,12 @@ int vrt_denoise(vrt_ctx *ctx, int width, int height, const void *d_rgba8, const 
 /* the same through HOST buffers, synchronous */
 int vrt_denoise_host(vrt_ctx *ctx, int width, int height, const uint8_t *rgba8, const int32_t *id_dist,
                      uint8_t *out_rgba8);
+/* EXTENSION: one whole frame of the reference's loop -- dispatch (src/main.cpp:946) then the display pass
+ * (:951-967) -- with both intermediate images kept on the device; only what the caller asks for comes back.
+ * HOST pointers, synchronous. out_shown_rgba8 receives what the reference puts on screen; out_rgba8 and
+ * out_id_dist (either may be NULL) the two images the dispatch wrote. */
+int vrt_dispatch_frame(vrt_ctx *ctx, int width, int height, int mode, uint8_t *out_shown_rgba8, uint8_t *out_rgba8,
+                       int32_t *out_id_dist);
 
 /* Per-launch timing of the dispatches that follow: a hipEvent pair is recorded
  * around each kernel launch, on the stream it is launched on, for up to

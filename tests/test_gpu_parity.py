@@ -548,3 +548,18 @@ def test_seeded_random_scenes_uniforms_and_cameras(ctx, V, O):
             hit_pixels += n_hit
     ctx.set_params(ctx.default_params())
     assert frames_with_hits >= 15 and hit_pixels > 5000, (frames_with_hits, hit_pixels)   # the sweep looked at geometry
+
+
+def test_fused_frame_call_equals_dispatch_then_display_pass(ctx, V, product_scenes):
+    """vrt_dispatch_frame keeps the two intermediate images on the device; all three results must equal the
+    two-call route, at a size off every tile edge."""
+    tex, dim = product_scenes["monu9"]
+    W, H = 203, 117
+    _setup(ctx, V, tex, dim, (48.5, 60.5, 170.5, -90.0, -12.0), W, H)
+    for mode in (0, 1, 2):
+        rgba, idd = ctx.dispatch(W, H, mode)
+        shown = ctx.denoise(rgba, idd)
+        f_shown, f_rgba, f_id = ctx.dispatch_frame(W, H, mode)
+        _assert_same(f_rgba, rgba, f"fused frame mode {mode} rgba8")
+        _assert_same(f_id, idd, f"fused frame mode {mode} id/dist")
+        _assert_same(f_shown, shown, f"fused frame mode {mode} shown")

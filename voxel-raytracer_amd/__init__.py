@@ -123,6 +123,7 @@ def hip_lib():
         L.vrt_denoise.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vrt_denoise_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vrt_debug_set_denoise_variant.argtypes = [C.c_void_p, C.c_int]
+        L.vrt_dispatch_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vrt_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.vrt_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
         L.vrt_stream.restype = C.c_void_p
@@ -399,6 +400,15 @@ class Context:
         out = np.zeros_like(rgba)
         self._chk(self._L.vrt_denoise_host(self._h, w, h, rgba.ctypes.data, idd.ctypes.data, out.ctypes.data))
         return out
+
+    def dispatch_frame(self, width, height, mode=MODE_FULL):
+        """Dispatch + display pass with the intermediates kept on the device -> (shown, rgba8, id_dist) host arrays."""
+        shown = np.zeros((height, width, 4), np.uint8)
+        rgba = np.zeros((height, width, 4), np.uint8)
+        idd = np.zeros((height, width, 2), np.int32)
+        self._chk(self._L.vrt_dispatch_frame(self._h, width, height, mode, shown.ctypes.data, rgba.ctypes.data,
+                                             idd.ctypes.data))
+        return shown, rgba, idd
 
     def denoise_device(self, width, height, d_rgba, d_id, d_out, stream=None):
         self._chk(self._L.vrt_denoise(self._h, width, height, d_rgba, d_id, d_out, stream))

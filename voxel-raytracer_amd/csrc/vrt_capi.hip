@@ -74,6 +74,7 @@ struct vrt_ctx {
     // scratch outputs for the host-buffer dispatch
     void *d_rgba = nullptr;
     void *d_id = nullptr;
+    void *d_shown = nullptr;
     size_t scratch_pixels = 0;
     // optional per-launch hipEvent pairs (vrt_set_profiling)
     bool profiling = false;
@@ -332,6 +333,7 @@ void vrt_destroy(vrt_ctx *c) {
     if (c->d_cells) (void)hipFree(c->d_cells);
     if (c->d_rgba) (void)hipFree(c->d_rgba);
     if (c->d_id) (void)hipFree(c->d_id);
+    if (c->d_shown) (void)hipFree(c->d_shown);
     for (auto &e : c->prof_events) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -464,6 +466,25 @@ int vrt_set_variant(vrt_ctx *c, int variant) {
     return VRT_OK;
 }
 
+
+namespace {
+// device images behind the host-buffer entry points: rgba8, (id, dist) and the displayed rgba8
+int ensure_scratch(vrt_ctx *c, size_t px) {
+    if (px <= c->scratch_pixels) return VRT_OK;
+    VRT_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->d_rgba) VRT_HIP(c, hipFree(c->d_rgba));
+    if (c->d_id) VRT_HIP(c, hipFree(c->d_id));
+    if (c->d_shown) VRT_HIP(c, hipFree(c->d_shown));
+    c->d_rgba = c->d_id = c->d_shown = nullptr;
+    c->scratch_pixels = 0;
+    VRT_HIP(c, hipMalloc(&c->d_rgba, px * 4));
+    VRT_HIP(c, hipMalloc(&c->d_id, px * 8));
+    VRT_HIP(c, hipMalloc(&c->d_shown, px * 4));
+    c->scratch_pixels = px;
+    return VRT_OK;
+}
+}  // namespace
+
 int vrt_dispatch_rows(vrt_ctx *c, int width, int height, int row_begin, int row_end, int mode, void *d_rgba8,
                       void *d_id_dist, void *stream) {
     int r = check_frame(c, width, height);
@@ -502,16 +523,8 @@ int vrt_dispatch(vrt_ctx *c, int width, int height, int mode, uint8_t *out_rgba8
     if (r) return r;
     VRT_HIP(c, hipSetDevice(c->device));
     const size_t px = (size_t)width * (size_t)height;
-    if (px > c->scratch_pixels) {
-        VRT_HIP(c, hipStreamSynchronize(c->stream));
-        if (c->d_rgba) VRT_HIP(c, hipFree(c->d_rgba));
-        if (c->d_id) VRT_HIP(c, hipFree(c->d_id));
-        c->d_rgba = c->d_id = nullptr;
-        c->scratch_pixels = 0;
-        VRT_HIP(c, hipMalloc(&c->d_rgba, px * 4));
-        VRT_HIP(c, hipMalloc(&c->d_id, px * 8));
-        c->scratch_pixels = px;
-    }
+    r = ensure_scratch(c, px);
+    if (r) return r;
     r = enqueue(c, width, height, 0, height, height, 0, 0, mode, out_rgba8 ? c->d_rgba : nullptr,
                 out_id_dist ? c->d_id : nullptr, c->stream);
     if (r) return r;
@@ -576,19 +589,35 @@ int vrt_denoise_host(vrt_ctx *c, int width, int height, const uint8_t *rgba8, co
     if (!rgba8 || !id_dist || !out_rgba8) return fail(c, VRT_E_INVALID, "vrt_denoise_host: null buffer");
     VRT_HIP(c, hipSetDevice(c->device));
     const size_t px = (size_t)width * (size_t)height;
-    void *d_in = nullptr, *d_id = nullptr, *d_out = nullptr;
-    VRT_HIP(c, hipMalloc(&d_in, px * 4));
-    VRT_HIP(c, hipMalloc(&d_id, px * 8));
-    VRT_HIP(c, hipMalloc(&d_out, px * 4));
-    VRT_HIP(c, hipMemcpyAsync(d_in, rgba8, px * 4, hipMemcpyHostToDevice, c->stream));
-    VRT_HIP(c, hipMemcpyAsync(d_id, id_dist, px * 8, hipMemcpyHostToDevice, c->stream));
-    r = vrt_denoise(c, width, height, d_in, d_id, d_out, nullptr);
-    if (r == VRT_OK) {
-        VRT_HIP(c, hipMemcpyAsync(out_rgba8, d_out, px * 4, hipMemcpyDeviceToHost, c->stream));
-        VRT_HIP(c, hipStreamSynchronize(c->stream));
-    }
-    (void)hipFree(d_in); (void)hipFree(d_id); (void)hipFree(d_out);
-    return r;
+    r = ensure_scratch(c, px);
+    if (r) return r;
+    VRT_HIP(c, hipMemcpyAsync(c->d_rgba, rgba8, px * 4, hipMemcpyHostToDevice, c->stream));
+    VRT_HIP(c, hipMemcpyAsync(c->d_id, id_dist, px * 8, hipMemcpyHostToDevice, c->stream));
+    r = vrt_denoise(c, width, height, c->d_rgba, c->d_id, c->d_shown, nullptr);
+    if (r) return r;
+    VRT_HIP(c, hipMemcpyAsync(out_rgba8, c->d_shown, px * 4, hipMemcpyDeviceToHost, c->stream));
+    VRT_HIP(c, hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+
+int vrt_dispatch_frame(vrt_ctx *c, int width, int height, int mode, uint8_t *out_shown_rgba8, uint8_t *out_rgba8,
+                       int32_t *out_id_dist) {
+    int r = check_frame(c, width, height);
+    if (r) return r;
+    if (!out_shown_rgba8) return fail(c, VRT_E_INVALID, "vrt_dispatch_frame: null output");
+    VRT_HIP(c, hipSetDevice(c->device));
+    const size_t px = (size_t)width * (size_t)height;
+    r = ensure_scratch(c, px);
+    if (r) return r;
+    r = enqueue(c, width, height, 0, height, height, 0, 0, mode, c->d_rgba, c->d_id, c->stream);
+    if (r) return r;
+    r = vrt_denoise(c, width, height, c->d_rgba, c->d_id, c->d_shown, nullptr);
+    if (r) return r;
+    VRT_HIP(c, hipMemcpyAsync(out_shown_rgba8, c->d_shown, px * 4, hipMemcpyDeviceToHost, c->stream));
+    if (out_rgba8) VRT_HIP(c, hipMemcpyAsync(out_rgba8, c->d_rgba, px * 4, hipMemcpyDeviceToHost, c->stream));
+    if (out_id_dist) VRT_HIP(c, hipMemcpyAsync(out_id_dist, c->d_id, px * 8, hipMemcpyDeviceToHost, c->stream));
+    VRT_HIP(c, hipStreamSynchronize(c->stream));
+    return VRT_OK;
 }
 
 int vrt_synchronize(vrt_ctx *c) {
