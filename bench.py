@@ -217,6 +217,32 @@ def main():
         overlapped = {"streams": 2, "value": round(W * H * args.steps / e2 / 1e6, 2), "unit": "Mrays/s",
                       "ms_per_step": round(e2 / args.steps * 1e3, 5), "same_pixels": same}
 
+    # one GPU, informational: four frames per launch (vrt_dispatch_views). The launch duration is again a clean
+    # per-kernel figure (no neighbour on the GPU), so the roofline arithmetic of the contract applies to it as is
+    batched = None
+    if world == 1 and n_streams == 1 and not args.no_kernel_events:
+        F = 4
+        bufs = [plan.local_buffer(dev) for _ in range(2 * F)]
+        sets = [V.make_views([(ip, iv, cp) + plan.pointers(bufs[g * F + j]) for j in range(F)]) for g in range(2)]
+        stream0 = torch.cuda.current_stream(dev).cuda_stream
+        n_launch = (args.steps + F - 1) // F
+        for g in range(max(2, args.warmup // F)):
+            ctx.dispatch_views(W, H, args.tile_rows, rank, world, mode, sets[g & 1], stream0)
+        torch.cuda.synchronize(dev)
+        ctx.set_profiling(n_launch, every=2)
+        t0 = time.perf_counter()
+        for g in range(n_launch):
+            ctx.dispatch_views(W, H, args.tile_rows, rank, world, mode, sets[g & 1], stream0)
+        torch.cuda.synchronize(dev)
+        e3 = time.perf_counter() - t0
+        launch_ms = ctx.profile_read(n_launch)
+        ctx.set_profiling(0)
+        last = bufs[((n_launch - 1) & 1) * F + F - 1]
+        same = bool(torch.equal(last, pipe.local[(pipe.frame + 1) % 2].view(-1)[: last.numel()]))
+        batched = {"frames_per_launch": F, "value": round(W * H * n_launch * F / e3 / 1e6, 2), "unit": "Mrays/s",
+                   "ms_per_step": round(e3 / (n_launch * F) * 1e3, 5), "same_pixels": same,
+                   "launch_avg_ms": round(float(launch_ms.mean()), 5) if len(launch_ms) else None}
+
     if rank == 0:
         frames = json.load(open(os.path.join(ROOT, "tests", "golden", "frames.json")))["frames"]
         key = {"dragon": "dragon_1080p", "monu9": "monu9_720p", "nature": "nature_4k"}.get(args.map, "-") + f"/mode{mode}"
@@ -257,6 +283,9 @@ def main():
                         "kernel": "trace_kernel", "kernel_avg_ms": round(avg_ms, 5),
                         "algorithmic_bytes_per_launch": b_algo,
                         "compulsory_bytes_per_launch": int(tex.size + 12 * W * plan.rows_local)}
+        if batched and roofline and batched["launch_avg_ms"]:
+            b4 = batched["frames_per_launch"] * roofline["algorithmic_bytes_per_launch"]
+            batched["roofline_frac"] = round(b4 / (batched["launch_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         out = {
             "metric": metric_name(),
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -275,6 +304,7 @@ def main():
             "roofline": roofline,
             "pixels_match_oracle_golden": check,
             "overlapped_frames": overlapped,
+            "batched_views": batched,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, tex, dim, (ip, iv, cp))

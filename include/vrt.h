@@ -114,6 +114,22 @@ int vrt_dispatch_shard(vrt_ctx *ctx, int width, int height, int tile_rows, int s
 /* rows (and pixels = rows*width) a shard owns under that scheme */
 int vrt_shard_rows(int height, int tile_rows, int shard, int n_shards);
 
+/* EXTENSION: up to 4 views of the uploaded scene in ONE launch -- frames that are known together (a stereo pair,
+ * the next frames of a camera path, the views of a rig). Each view brings its own camera block (what
+ * vrt_set_camera takes) and its own compact shard buffers (what vrt_dispatch_shard takes); scene, uniforms and the
+ * row sharding are shared. Pixels are those of n_views separate vrt_dispatch_shard calls; the launch is shorter
+ * than their sum because one view's last waves no longer drain an otherwise idle chip. DEVICE pointers,
+ * stream-ordered, returns after enqueueing. */
+typedef struct vrt_view {
+    float inv_projection[16];
+    float inv_view[16];
+    float camera_pos[4];
+    void *d_rgba8;      /* rows_of_shard * width packed rgba8, or NULL */
+    void *d_id_dist;    /* rows_of_shard * width int2 (voxelID, dist), or NULL */
+} vrt_view;
+int vrt_dispatch_views(vrt_ctx *ctx, int width, int height, int tile_rows, int shard, int n_shards, int mode,
+                       const vrt_view *views, int n_views, void *stream);
+
 /* Repeats vrt_dispatch_rows `iters` times on `stream` with a hipEvent pair
  * around every launch and returns each launch's duration (ms) in ms_out[iters].
  * Blocks until done. */

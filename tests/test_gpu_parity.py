@@ -563,3 +563,43 @@ def test_fused_frame_call_equals_dispatch_then_display_pass(ctx, V, product_scen
         _assert_same(f_rgba, rgba, f"fused frame mode {mode} rgba8")
         _assert_same(f_id, idd, f"fused frame mode {mode} id/dist")
         _assert_same(f_shown, shown, f"fused frame mode {mode} shown")
+
+
+def test_views_in_one_launch_equal_separate_dispatches(ctx, V, product_scenes):
+    """vrt_dispatch_views: 1..4 cameras rendered by ONE launch (and by the per-view fallback of the other kernel
+    variants) give the pixels of separate vrt_dispatch_shard calls, whole frame and as a row shard."""
+    import torch
+    tex, dim = product_scenes["dragon"]
+    W, H = 200, 117
+    poses = [(63.5, 60.5, 140.5, -90.0, -10.0), (20.5, 70.5, 120.5, -70.0, -20.0), (100.5, 30.5, 90.5, -120.0, 5.0),
+             (63.5, 200.5, 30.5, -90.0, -80.0)]
+    cams = [V.camera_block(p[:3], p[3], p[4], W, H)[:3] for p in poses]
+    ctx.upload_octree(tex, dim)
+    ctx.set_params(ctx.default_params())
+    for (shard, n_shards) in [(0, 1), (1, 3)]:
+        rows = V.shard_rows(H, 8, shard, n_shards)
+        for mode in (0, 1, 2):
+            ref = []
+            for cam in cams:
+                ctx.set_camera(*cam)
+                r = torch.zeros((rows, W), dtype=torch.int32, device="cuda")
+                i = torch.zeros((rows, W, 2), dtype=torch.int32, device="cuda")
+                torch.cuda.synchronize()
+                ctx.dispatch_shard(W, H, 8, shard, n_shards, mode, r.data_ptr(), i.data_ptr())
+                ctx.synchronize()
+                ref.append((r.cpu().numpy(), i.cpu().numpy()))
+            for variant in (0, 4):                                   # 4: record-array kernels -> one launch per view
+                ctx.set_variant(variant)
+                for n in (1, 2, 4):
+                    outs = [(torch.zeros((rows, W), dtype=torch.int32, device="cuda"),
+                             torch.zeros((rows, W, 2), dtype=torch.int32, device="cuda")) for _ in range(n)]
+                    torch.cuda.synchronize()
+                    ctx.dispatch_views(W, H, 8, shard, n_shards, mode,
+                                       [cams[k] + (outs[k][0].data_ptr(), outs[k][1].data_ptr()) for k in range(n)])
+                    ctx.synchronize()
+                    for k in range(n):
+                        assert np.array_equal(outs[k][0].cpu().numpy(), ref[k][0]), (shard, mode, variant, n, k)
+                        assert np.array_equal(outs[k][1].cpu().numpy(), ref[k][1]), (shard, mode, variant, n, k)
+            ctx.set_variant(0)
+    with pytest.raises(V.VrtError):
+        ctx.dispatch_views(W, H, 8, 0, 1, 0, [cams[0] + (0, 0)] * 5)

@@ -31,17 +31,26 @@ def main():
         bufs = [plan.local_buffer(dev) for _ in range(2)]
         ptrs = [plan.pointers(b) for b in bufs]
         side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
-        for mode in ("one stream", "two streams"):
+        cam = (ip, iv, cp)
+        bufs4 = [plan.local_buffer(dev) for _ in range(8)]
+        ptrs4 = [plan.pointers(b) for b in bufs4]
+        for mode in ("one stream", "two streams", "2 views/launch", "4 views/launch"):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for i in range(steps):
-                p = ptrs[i & 1]
-                ctx.dispatch_shard(W, H, 8, 0, world, 0, p[0], p[1],
-                                   stream if mode == "one stream" else side[i & 1].cuda_stream)
+            if mode.endswith("launch"):
+                f = int(mode[0])
+                sets = [V.make_views([cam + ptrs4[(g * f + j) % 8] for j in range(f)]) for g in range(8 // f)]
+                for i in range(steps // f):
+                    ctx.dispatch_views(W, H, 8, 0, world, 0, sets[i % len(sets)], stream)
+            else:
+                for i in range(steps):
+                    p = ptrs[i & 1]
+                    ctx.dispatch_shard(W, H, 8, 0, world, 0, p[0], p[1],
+                                       stream if mode == "one stream" else side[i & 1].cuda_stream)
             t1 = time.perf_counter()
             torch.cuda.synchronize()
             t2 = time.perf_counter()
-            print("N=%d shard, %-11s: %7.2f us/step total, host enqueue %7.2f us/step" %
+            print("N=%d shard, %-14s: %7.2f us/step total, host enqueue %7.2f us/step" %
                   (world, mode, (t2 - t0) / steps * 1e6, (t1 - t0) / steps * 1e6))
 
 

@@ -38,6 +38,12 @@ class Params(C.Structure):
                 ("global_light", C.c_float * 4), ("light_dir", C.c_float * 3), ("highlighted", C.c_int32 * 3)]
 
 
+class View(C.Structure):
+    """vrt_view: one camera block and the two device images it renders into"""
+    _fields_ = [("inv_projection", C.c_float * 16), ("inv_view", C.c_float * 16), ("camera_pos", C.c_float * 4),
+                ("d_rgba8", C.c_void_p), ("d_id_dist", C.c_void_p)]
+
+
 class SceneInfo(C.Structure):
     _fields_ = [("tex_dim", C.c_uint32), ("n_texels", C.c_uint32), ("n_records", C.c_uint32),
                 ("n_internal", C.c_uint32), ("n_leaves", C.c_uint32), ("max_depth", C.c_uint32),
@@ -123,6 +129,8 @@ def hip_lib():
         L.vrt_denoise.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vrt_denoise_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vrt_debug_set_denoise_variant.argtypes = [C.c_void_p, C.c_int]
+        L.vrt_dispatch_views.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.POINTER(View), C.c_int, C.c_void_p]
         L.vrt_dispatch_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vrt_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.vrt_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
@@ -401,6 +409,14 @@ class Context:
         self._chk(self._L.vrt_denoise_host(self._h, w, h, rgba.ctypes.data, idd.ctypes.data, out.ctypes.data))
         return out
 
+    def dispatch_views(self, width, height, tile_rows, shard, n_shards, mode, views, stream=None):
+        """views: sequence of (inv_proj, inv_view, cam_pos, d_rgba8, d_id_dist) or a prepared (View * n) array;
+        one launch renders them all (vrt_dispatch_views)."""
+        if not isinstance(views, C.Array):
+            views = make_views(views)
+        self._chk(self._L.vrt_dispatch_views(self._h, width, height, tile_rows, shard, n_shards, mode, views, len(views),
+                                             stream))
+
     def dispatch_frame(self, width, height, mode=MODE_FULL):
         """Dispatch + display pass with the intermediates kept on the device -> (shown, rgba8, id_dist) host arrays."""
         shown = np.zeros((height, width, 4), np.uint8)
@@ -430,6 +446,17 @@ class Context:
         out = np.zeros_like(x)
         self._chk(self._L.vrt_debug_math(self._h, op, x.ctypes.data, y.ctypes.data, out.ctypes.data, x.size))
         return out
+
+
+def make_views(views):
+    """(inv_proj, inv_view, cam_pos, d_rgba8, d_id_dist) tuples -> ctypes array of vrt_view"""
+    arr = (View * len(views))()
+    for v, (ip, iv, cp, p_rgba, p_id) in zip(arr, views):
+        v.inv_projection[:] = [float(x) for x in ip]
+        v.inv_view[:] = [float(x) for x in iv]
+        v.camera_pos[:] = [float(x) for x in cp]
+        v.d_rgba8, v.d_id_dist = p_rgba, p_id
+    return arr
 
 
 def shard_rows(height, tile_rows, shard, n_shards):

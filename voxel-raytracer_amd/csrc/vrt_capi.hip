@@ -108,18 +108,19 @@ int fail(vrt_ctx *c, int code, const std::string &msg) {
             return fail((c), VRT_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-template <int MODE, class TRAV, int TW, int BLOCK, int WPE, bool PERSIST = false>
-hipError_t launch_one(const vrt::KArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
+template <int MODE, class TRAV, int TW, int BLOCK, int WPE, bool PERSIST = false, bool VIEWS = false>
+hipError_t launch_one(const vrt::KArgs &a, int grid, size_t lds_bytes, hipStream_t s) {  // grid.y = a.n_views
     if (lds_bytes > 48 * 1024) {  // above the default dynamic-LDS ceiling: opt in (CDNA4 has 160 KiB per CU)
         static bool raised = false;
         if (!raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST, VIEWS>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             if (e != hipSuccess) return e;
             raised = true;
         }
     }
-    hipLaunchKernelGGL((vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST>), dim3(grid), dim3(BLOCK), lds_bytes, s, a);
+    hipLaunchKernelGGL((vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST, VIEWS>), dim3(grid, VIEWS ? a.n_views : 1), dim3(BLOCK),
+                       lds_bytes, s, a);
     return hipGetLastError();
 }
 
@@ -161,10 +162,15 @@ hipError_t launch_mode(const Variant &v, const vrt::KArgs &a, int grid, size_t l
 }
 
 // Builds the kernel arguments for local rows [0, n_rows) and enqueues one launch.
+int enqueue_one_view(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_rows, int row_stride, int compact,
+                     int mode, hipStream_t s, const vrt_view &view);
+
+// views == nullptr: one view, the context's camera (vrt_set_camera) rendering into d_rgba / d_id.
 int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_rows, int row_stride, int compact,
-            int mode, void *d_rgba, void *d_id, hipStream_t s) {
+            int mode, void *d_rgba, void *d_id, hipStream_t s, const vrt_view *views = nullptr, int n_views = 1) {
     if (!c->have_scene) return fail(c, VRT_E_STATE, "vrt_dispatch: no octree uploaded (call vrt_upload_octree first)");
-    if (!c->have_camera) return fail(c, VRT_E_STATE, "vrt_dispatch: no camera set (call vrt_set_camera first)");
+    if (!views && !c->have_camera) return fail(c, VRT_E_STATE, "vrt_dispatch: no camera set (call vrt_set_camera first)");
+    if (n_views < 1 || n_views > vrt::kMaxViews) return fail(c, VRT_E_INVALID, "vrt_dispatch_views: 1 to 4 views per launch");
     if (mode != VRT_MODE_PRIMARY && mode != VRT_MODE_PRIMARY_SHADOW && mode != VRT_MODE_FULL)
         return fail(c, VRT_E_INVALID, "unknown mode");
     if (n_rows <= 0) return VRT_OK;
@@ -203,9 +209,16 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
         v.use_lds = false; v.tw = 8; v.block = 256; v.wpe = 1; v.lds_cap = 0;
     }
     vrt::KArgs a;
-    std::memcpy(a.inv_proj, c->inv_proj, sizeof a.inv_proj);
-    std::memcpy(a.inv_view, c->inv_view, sizeof a.inv_view);
-    std::memcpy(a.cam_pos, c->cam_pos, sizeof a.cam_pos);
+    std::memset(a.views, 0, sizeof a.views);
+    a.n_views = n_views;
+    for (int i = 0; i < n_views; ++i) {
+        vrt::View &w = a.views[i];
+        std::memcpy(w.inv_proj, views ? views[i].inv_projection : c->inv_proj, sizeof w.inv_proj);
+        std::memcpy(w.inv_view, views ? views[i].inv_view : c->inv_view, sizeof w.inv_view);
+        std::memcpy(w.cam_pos, views ? views[i].camera_pos : c->cam_pos, sizeof w.cam_pos);
+        w.out_rgba = (uint32_t *)(views ? views[i].d_rgba8 : d_rgba);
+        w.out_id = (int2 *)(views ? views[i].d_id_dist : d_id);
+    }
     a.voxel_scale = c->params.voxel_scale;
     for (int i = 0; i < 3; ++i) {
         a.wmin[i] = c->params.world_min[i];
@@ -225,8 +238,6 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     a.nodes = c->d_nodes;
     a.n_records = c->info.n_records;
     a.lds_records = v.use_lds ? (c->info.n_records < v.lds_cap ? c->info.n_records : v.lds_cap) : 0u;
-    a.out_rgba = (uint32_t *)d_rgba;
-    a.out_id = (int2 *)d_id;
     a.cells = c->d_cells;
     a.n_roots = c->wide_ok ? (uint32_t)c->wide.roots.size() : 0u;
     for (int i = 0; i < 8; ++i) {
@@ -249,7 +260,29 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     const bool prof = c->profiling && (c->prof_seen++ % c->prof_stride) == 0 && (c->prof_count + 1) * 2 <= c->prof_events.size();
     if (prof) VRT_HIP(c, hipEventRecord(c->prof_events[2 * c->prof_count], s));
     hipError_t e;
-    if (mode == VRT_MODE_FULL) {
+    const bool default_shape = v.trav == 3 && !v.use_lds && v.tw == 8 && v.block == 256 && v.blocks_per_cu == 0;
+    if (n_views > 1 && default_shape && (mode == VRT_MODE_FULL || v.wpe == 6)) {
+        // several views in one launch: instantiated for the default traversal
+        if (mode == VRT_MODE_FULL) e = launch_one<2, vrt::v3::Trav, 8, 256, 1, false, true>(a, (int)grid, 0, s);
+        else if (mode == VRT_MODE_PRIMARY) e = launch_one<0, vrt::v3::Trav, 8, 256, 6, false, true>(a, (int)grid, 0, s);
+        else e = launch_one<1, vrt::v3::Trav, 8, 256, 6, false, true>(a, (int)grid, 0, s);
+    } else if (n_views > 1) {
+        // any other variant or a scene the wide layout cannot express: one launch per view, same pixels
+        if (prof) {  // the bracket below would straddle the recursion: close it around the whole group instead
+            for (int i = 0; i < n_views; ++i) {
+                const int r = enqueue_one_view(c, width, height, row0, n_rows, tile_rows, row_stride, compact, mode, s, views[i]);
+                if (r) return r;
+            }
+            VRT_HIP(c, hipEventRecord(c->prof_events[2 * c->prof_count + 1], s));
+            ++c->prof_count;
+            return VRT_OK;
+        }
+        for (int i = 0; i < n_views; ++i) {
+            const int r = enqueue_one_view(c, width, height, row0, n_rows, tile_rows, row_stride, compact, mode, s, views[i]);
+            if (r) return r;
+        }
+        return VRT_OK;
+    } else if (mode == VRT_MODE_FULL) {
         // the full path tracer is instantiated for the default traversal and for the explicit-AABB baseline only
         if (v.trav == 3) e = launch_one<2, vrt::v3::Trav, 8, 256, 1>(a, (int)grid, 0, s);
         else if (v.trav == 2) e = launch_one<2, vrt::v2::Trav<false>, 8, 256, 1>(a, (int)grid, 0, s);
@@ -265,6 +298,15 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     }
     c->info.lds_records = a.lds_records;
     return VRT_OK;
+}
+
+int enqueue_one_view(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_rows, int row_stride, int compact,
+                     int mode, hipStream_t s, const vrt_view &view) {
+    const bool was = c->profiling;
+    c->profiling = false;  // the caller brackets the group
+    const int r = enqueue(c, width, height, row0, n_rows, tile_rows, row_stride, compact, mode, nullptr, nullptr, s, &view, 1);
+    c->profiling = was;
+    return r;
 }
 
 int check_frame(vrt_ctx *c, int width, int height) {
@@ -516,6 +558,18 @@ int vrt_dispatch_shard(vrt_ctx *c, int width, int height, int tile_rows, int sha
     VRT_HIP(c, hipSetDevice(c->device));
     return enqueue(c, width, height, shard * tile_rows, rows, tile_rows, tile_rows * n_shards, 1, mode, d_rgba8,
                    d_id_dist, stream ? (hipStream_t)stream : c->stream);
+}
+
+int vrt_dispatch_views(vrt_ctx *c, int width, int height, int tile_rows, int shard, int n_shards, int mode,
+                       const vrt_view *views, int n_views, void *stream) {
+    int r = check_frame(c, width, height);
+    if (r) return r;
+    if (!views) return fail(c, VRT_E_INVALID, "vrt_dispatch_views: null views");
+    const int rows = vrt_shard_rows(height, tile_rows, shard, n_shards);
+    if (rows < 0) return fail(c, VRT_E_INVALID, "vrt_dispatch_views: bad tile_rows/shard/n_shards");
+    VRT_HIP(c, hipSetDevice(c->device));
+    return enqueue(c, width, height, shard * tile_rows, rows, tile_rows, tile_rows * n_shards, 1, mode, nullptr, nullptr,
+                   stream ? (hipStream_t)stream : c->stream, views, n_views);
 }
 
 int vrt_dispatch(vrt_ctx *c, int width, int height, int mode, uint8_t *out_rgba8, int32_t *out_id_dist) {

@@ -20,11 +20,23 @@ namespace vrt {
 struct F3 { float x, y, z; };
 struct I3 { int x, y, z; };
 
-// Kernel arguments: passed by value (kernarg segment -> scalar loads, wave-uniform).
-struct KArgs {
+// One camera and the two images it renders into. A launch carries up to kMaxViews of them (blockIdx.y selects
+// the view): frames of one scene that are known together -- a stereo pair, the next frames of a camera path, the
+// views of a light-field rig -- share one launch, so the drain of one view's last waves is filled by the next
+// view's first instead of idling the chip between launches.
+constexpr int kMaxViews = 4;
+struct View {
     float inv_proj[16];
     float inv_view[16];
     float cam_pos[4];
+    uint32_t *out_rgba;       // packed R | G<<8 | B<<16 | A<<24
+    int2 *out_id;             // (voxelID, dist)
+};
+
+// Kernel arguments: passed by value (kernarg segment -> scalar loads, wave-uniform).
+struct KArgs {
+    View views[kMaxViews];
+    int n_views;              // gridDim.y
     float voxel_scale;
     int wmin[3];
     int wmax[3];
@@ -40,8 +52,6 @@ struct KArgs {
     const uint2 *nodes;       // level-ordered records (vrt_layout.h), root = record 0
     uint32_t n_records;
     uint32_t lds_records;     // prefix of `nodes` staged in LDS by each workgroup
-    uint32_t *out_rgba;       // packed R | G<<8 | B<<16 | A<<24
-    int2 *out_id;             // (voxelID, dist)
     // wide layout (vrt_layout.h): 64 cells per node; roots = octree records where a wide tree starts
     const uint2 *cells;
     uint32_t n_roots;
@@ -141,18 +151,18 @@ VRT_DEV Decoded decode_leaf(const float *unorm, uint32_t w0, uint32_t w1) {
 // One pixel: ray generation (comp:624-641), primary-ray pathTrace, packing of the two outputs.
 // TRAV supplies the traversal: eye_medium(), march(), shadow(). MODE: 0 primary, 1 primary + shadow ray.
 template <int MODE, class TRAV>
-VRT_DEV void trace_pixel(const KArgs &a, const typename TRAV::Ctx &tc_, const float *unorm, int px, int py, uint32_t &rgba, int2 &idd) {
+VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, const float *unorm, int px, int py, uint32_t &rgba, int2 &idd) {
     const float kPI = 3.14159265359f;
     float u = ((float)px / (float)a.width) * 2.0f - 1.0f;
     float v = ((float)py / (float)a.height) * 2.0f - 1.0f;
     float view[4];
-    mat_vec(a.inv_proj, u, v, -1.0f, 1.0f, view);
+    mat_vec(vw.inv_proj, u, v, -1.0f, 1.0f, view);
     if (__builtin_fabsf(view[3]) > 1e-6f) { float w = view[3]; view[0] = view[0] / w; view[1] = view[1] / w; view[2] = view[2] / w; view[3] = view[3] / w; }
     F3 vd = normalize3(F3{view[0], view[1], view[2]});
     float wd4[4];
-    mat_vec(a.inv_view, vd.x, vd.y, vd.z, 0.0f, wd4);
+    mat_vec(vw.inv_view, vd.x, vd.y, vd.z, 0.0f, wd4);
     F3 ray_dir = normalize3(F3{wd4[0], wd4[1], wd4[2]});
-    F3 ray_origin{a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]};
+    F3 ray_origin{vw.cam_pos[0], vw.cam_pos[1], vw.cam_pos[2]};
 
     int voxel_id = 0;
     int pixel_dist = a.wmax[0] - a.wmin[0];
@@ -250,13 +260,15 @@ VRT_DEV void trace_pixel(const KArgs &a, const typename TRAV::Ctx &tc_, const fl
 
 namespace full {  // MODE 2, defined in vrt_full.hip.h
 template <class TRAV>
-__device__ void trace_pixel_full(const KArgs &a, const typename TRAV::Ctx &tc_, const float *unorm, int px, int py, uint32_t &rgba, int2 &idd);
+__device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, const float *unorm, int px, int py, uint32_t &rgba, int2 &idd);
 }
 
 // One lane per pixel; a wave covers a TW x TH pixel tile (TW*TH == 64) so the 64 rays of a wave
 // stay spatially coherent; workgroups walk tiles with a grid-stride loop.
 // WPE: waves per SIMD the register allocator must leave room for (1 = no constraint beyond BLOCK).
-template <int MODE, class TRAV, int TW, int BLOCK, int WPE = 1, bool PERSIST = false>
+// VIEWS: the launch carries several views (gridDim.y); without it the view index is the constant 0, which keeps
+// the camera loads at fixed kernarg offsets (11 VGPRs fewer on gfx950: SGPR pressure spills into vector lanes).
+template <int MODE, class TRAV, int TW, int BLOCK, int WPE = 1, bool PERSIST = false, bool VIEWS = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) void trace_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint2 lds_dyn[];
     constexpr int TH = 64 / TW;
@@ -283,11 +295,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
             int py = a.row0 + (j / a.tile_rows) * a.row_stride + (j % a.tile_rows);
             uint32_t rgba;
             int2 idd;
-            if constexpr (MODE == 2) full::trace_pixel_full<TRAV>(a, tc_, unorm, px, py, rgba, idd);
-            else trace_pixel<MODE, TRAV>(a, tc_, unorm, px, py, rgba, idd);
+            const View &vw = a.views[VIEWS ? blockIdx.y : 0u];
+            if constexpr (MODE == 2) full::trace_pixel_full<TRAV>(a, vw, tc_, unorm, px, py, rgba, idd);
+            else trace_pixel<MODE, TRAV>(a, vw, tc_, unorm, px, py, rgba, idd);
             size_t o = (size_t)(a.compact ? j : py) * (size_t)a.width + (size_t)px;
-            if (a.out_rgba) a.out_rgba[o] = rgba;
-            if (a.out_id) a.out_id[o] = idd;
+            if (vw.out_rgba) vw.out_rgba[o] = rgba;
+            if (vw.out_id) vw.out_id[o] = idd;
         }
         if constexpr (!PERSIST) break;
     }

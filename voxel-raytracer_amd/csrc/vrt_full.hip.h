@@ -151,7 +151,7 @@ VRT_DEV RayS make_ray(F3 o, F3 d, float iof, float w, const float tint[3], float
 }
 
 template <class TRAV>
-__device__ void trace_pixel_full(const KArgs &a, const typename TRAV::Ctx &tc_, const float *unorm, int px, int py, uint32_t &rgba, int2 &idd) {
+__device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, const float *unorm, int px, int py, uint32_t &rgba, int2 &idd) {
     const float kPI = 3.14159265359f;
     const float sky[3] = {0.5f, 0.7f, 1.0f};
     const float kSun = 3.0f;
@@ -159,13 +159,13 @@ __device__ void trace_pixel_full(const KArgs &a, const typename TRAV::Ctx &tc_, 
     float u = ((float)px / (float)a.width) * 2.0f - 1.0f;
     float v = ((float)py / (float)a.height) * 2.0f - 1.0f;
     float view[4];
-    mat_vec(a.inv_proj, u, v, -1.0f, 1.0f, view);
+    mat_vec(vw.inv_proj, u, v, -1.0f, 1.0f, view);
     if (__builtin_fabsf(view[3]) > 1e-6f) { float w = view[3]; view[0] = view[0] / w; view[1] = view[1] / w; view[2] = view[2] / w; view[3] = view[3] / w; }
     F3 vd = normalize3(F3{view[0], view[1], view[2]});
     float wd4[4];
-    mat_vec(a.inv_view, vd.x, vd.y, vd.z, 0.0f, wd4);
+    mat_vec(vw.inv_view, vd.x, vd.y, vd.z, 0.0f, wd4);
     F3 ray_dir = normalize3(F3{wd4[0], wd4[1], wd4[2]});
-    const F3 ray_origin{a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]};
+    const F3 ray_origin{vw.cam_pos[0], vw.cam_pos[1], vw.cam_pos[2]};
 
     int voxel_id = 0;
     int pixel_dist = a.wmax[0] - a.wmin[0];
