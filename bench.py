@@ -111,6 +111,10 @@ def main():
                     help="HIP streams the frames alternate between (2: the drain of one launch overlaps the start of the "
                          "next). 0 = 1 at one GPU, where the per-launch duration feeds the roofline and must not be "
                          "inflated by a neighbour, and 2 with more ranks, where a launch is a fraction of a frame")
+    ap.add_argument("--extras", action="store_true",
+                    help="one GPU: after the timed region also time the same frames alternating between two streams "
+                         "(overlapped_frames) and four per launch (batched_views). Off by default so that a rocprofv3 "
+                         "kernel trace of the default command holds the timed region's launches only")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured path); gloo only rehearses the N>1 code path on a "
                          "box whose ranks share one GPU (collective staged through host memory)")
@@ -199,7 +203,7 @@ def main():
     # one GPU, informational: the same K frames alternating between two streams (no per-launch events; the figure the
     # headline would become if overlapped launches were allowed to blur the per-kernel duration the roofline uses)
     overlapped = None
-    if world == 1 and n_streams == 1:
+    if args.extras and world == 1 and n_streams == 1:
         pipe2 = shd.FramePipeline(plan, dev, gather=args.gather, streams=2)
         for it in range(args.warmup + args.steps):
             if it == args.warmup:
@@ -220,7 +224,7 @@ def main():
     # one GPU, informational: four frames per launch (vrt_dispatch_views). The launch duration is again a clean
     # per-kernel figure (no neighbour on the GPU), so the roofline arithmetic of the contract applies to it as is
     batched = None
-    if world == 1 and n_streams == 1 and not args.no_kernel_events:
+    if args.extras and world == 1 and n_streams == 1 and not args.no_kernel_events:
         F = 4
         bufs = [plan.local_buffer(dev) for _ in range(2 * F)]
         sets = [V.make_views([(ip, iv, cp) + plan.pointers(bufs[g * F + j]) for j in range(F)]) for g in range(2)]
