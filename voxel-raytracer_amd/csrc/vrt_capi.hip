@@ -108,25 +108,24 @@ int fail(vrt_ctx *c, int code, const std::string &msg) {
             return fail((c), VRT_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-template <int MODE, class TRAV, int TW, int BLOCK, int WPE, bool PERSIST = false, bool VIEWS = false>
-hipError_t launch_one(const vrt::KArgs &a, int grid, size_t lds_bytes, hipStream_t s) {  // grid.y = a.n_views
+template <int MODE, class TRAV, int TW, int BLOCK, int WPE, bool PERSIST = false>
+hipError_t launch_one(const vrt::KArgs &a, const vrt::ViewSet &vs, int grid, size_t lds_bytes, hipStream_t s) {  // grid.y = a.n_views
     if (lds_bytes > 48 * 1024) {  // above the default dynamic-LDS ceiling: opt in (CDNA4 has 160 KiB per CU)
         static bool raised = false;
         if (!raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST, VIEWS>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             if (e != hipSuccess) return e;
             raised = true;
         }
     }
-    hipLaunchKernelGGL((vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST, VIEWS>), dim3(grid, VIEWS ? a.n_views : 1), dim3(BLOCK),
-                       lds_bytes, s, a);
+    hipLaunchKernelGGL((vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST>), dim3(grid, a.n_views), dim3(BLOCK), lds_bytes, s, a, vs);
     return hipGetLastError();
 }
 
 // The instantiated (traversal, LDS prefix, tile width, workgroup size, waves-per-SIMD) combinations.
 template <int MODE>
-hipError_t launch_mode(const Variant &v, const vrt::KArgs &a, int grid, size_t lds, hipStream_t s) {
+hipError_t launch_mode(const Variant &v, const vrt::KArgs &a, const vrt::ViewSet &vs, int grid, size_t lds, hipStream_t s) {
     using V1 = vrt::v1::Trav<false>;
     using V1L = vrt::v1::Trav<true>;
     using V2 = vrt::v2::Trav<false>;
@@ -134,37 +133,34 @@ hipError_t launch_mode(const Variant &v, const vrt::KArgs &a, int grid, size_t l
     using V3 = vrt::v3::Trav;
     if (v.blocks_per_cu > 0) {  // the persistent (grid-stride) form exists for one combination
         if (v.trav == 2 && !v.use_lds && v.tw == 8 && v.block == 256 && v.wpe == 1)
-            return launch_one<MODE, V2, 8, 256, 1, true>(a, grid, lds, s);
+            return launch_one<MODE, V2, 8, 256, 1, true>(a, vs, grid, lds, s);
         return hipErrorInvalidValue;
     }
     const int key = v.trav * 1000000 + (v.use_lds ? 100000 : 0) + v.tw * 1000 + (v.block / 64) * 10 + v.wpe;
     switch (key) {
-        case 1000000 + 8000 + 40 + 1: return launch_one<MODE, V1, 8, 256, 1>(a, grid, lds, s);
-        case 1100000 + 8000 + 40 + 1: return launch_one<MODE, V1L, 8, 256, 1>(a, grid, lds, s);
-        case 2000000 + 8000 + 40 + 1: return launch_one<MODE, V2, 8, 256, 1>(a, grid, lds, s);
-        case 2000000 + 8000 + 40 + 5: return launch_one<MODE, V2, 8, 256, 5>(a, grid, lds, s);
-        case 2000000 + 8000 + 40 + 6: return launch_one<MODE, V2, 8, 256, 6>(a, grid, lds, s);
-        case 2000000 + 8000 + 40 + 8: return launch_one<MODE, V2, 8, 256, 8>(a, grid, lds, s);
-        case 2000000 + 16000 + 40 + 1: return launch_one<MODE, V2, 16, 256, 1>(a, grid, lds, s);
-        case 2000000 + 8000 + 80 + 1: return launch_one<MODE, V2, 8, 512, 1>(a, grid, lds, s);
-        case 2000000 + 8000 + 10 + 1: return launch_one<MODE, V2, 8, 64, 1>(a, grid, lds, s);
-        case 2000000 + 8000 + 20 + 1: return launch_one<MODE, V2, 8, 128, 1>(a, grid, lds, s);
-        case 2100000 + 8000 + 40 + 1: return launch_one<MODE, V2L, 8, 256, 1>(a, grid, lds, s);
-        case 2100000 + 8000 + 160 + 1: return launch_one<MODE, V2L, 8, 1024, 1>(a, grid, lds, s);
-        case 3000000 + 8000 + 40 + 1: return launch_one<MODE, V3, 8, 256, 1>(a, grid, lds, s);
-        case 3000000 + 8000 + 40 + 6: return launch_one<MODE, V3, 8, 256, 6>(a, grid, lds, s);
-        case 3000000 + 8000 + 40 + 8: return launch_one<MODE, V3, 8, 256, 8>(a, grid, lds, s);
-        case 3000000 + 8000 + 10 + 1: return launch_one<MODE, V3, 8, 64, 1>(a, grid, lds, s);
-        case 3000000 + 8000 + 10 + 8: return launch_one<MODE, V3, 8, 64, 8>(a, grid, lds, s);
-        case 3000000 + 16000 + 40 + 1: return launch_one<MODE, V3, 16, 256, 1>(a, grid, lds, s);
+        case 1000000 + 8000 + 40 + 1: return launch_one<MODE, V1, 8, 256, 1>(a, vs, grid, lds, s);
+        case 1100000 + 8000 + 40 + 1: return launch_one<MODE, V1L, 8, 256, 1>(a, vs, grid, lds, s);
+        case 2000000 + 8000 + 40 + 1: return launch_one<MODE, V2, 8, 256, 1>(a, vs, grid, lds, s);
+        case 2000000 + 8000 + 40 + 5: return launch_one<MODE, V2, 8, 256, 5>(a, vs, grid, lds, s);
+        case 2000000 + 8000 + 40 + 6: return launch_one<MODE, V2, 8, 256, 6>(a, vs, grid, lds, s);
+        case 2000000 + 8000 + 40 + 8: return launch_one<MODE, V2, 8, 256, 8>(a, vs, grid, lds, s);
+        case 2000000 + 16000 + 40 + 1: return launch_one<MODE, V2, 16, 256, 1>(a, vs, grid, lds, s);
+        case 2000000 + 8000 + 80 + 1: return launch_one<MODE, V2, 8, 512, 1>(a, vs, grid, lds, s);
+        case 2000000 + 8000 + 10 + 1: return launch_one<MODE, V2, 8, 64, 1>(a, vs, grid, lds, s);
+        case 2000000 + 8000 + 20 + 1: return launch_one<MODE, V2, 8, 128, 1>(a, vs, grid, lds, s);
+        case 2100000 + 8000 + 40 + 1: return launch_one<MODE, V2L, 8, 256, 1>(a, vs, grid, lds, s);
+        case 2100000 + 8000 + 160 + 1: return launch_one<MODE, V2L, 8, 1024, 1>(a, vs, grid, lds, s);
+        case 3000000 + 8000 + 40 + 1: return launch_one<MODE, V3, 8, 256, 1>(a, vs, grid, lds, s);
+        case 3000000 + 8000 + 40 + 6: return launch_one<MODE, V3, 8, 256, 6>(a, vs, grid, lds, s);
+        case 3000000 + 8000 + 40 + 8: return launch_one<MODE, V3, 8, 256, 8>(a, vs, grid, lds, s);
+        case 3000000 + 8000 + 10 + 1: return launch_one<MODE, V3, 8, 64, 1>(a, vs, grid, lds, s);
+        case 3000000 + 8000 + 10 + 8: return launch_one<MODE, V3, 8, 64, 8>(a, vs, grid, lds, s);
+        case 3000000 + 16000 + 40 + 1: return launch_one<MODE, V3, 16, 256, 1>(a, vs, grid, lds, s);
         default: return hipErrorInvalidValue;
     }
 }
 
 // Builds the kernel arguments for local rows [0, n_rows) and enqueues one launch.
-int enqueue_one_view(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_rows, int row_stride, int compact,
-                     int mode, hipStream_t s, const vrt_view &view);
-
 // views == nullptr: one view, the context's camera (vrt_set_camera) rendering into d_rgba / d_id.
 int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_rows, int row_stride, int compact,
             int mode, void *d_rgba, void *d_id, hipStream_t s, const vrt_view *views = nullptr, int n_views = 1) {
@@ -209,10 +205,11 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
         v.use_lds = false; v.tw = 8; v.block = 256; v.wpe = 1; v.lds_cap = 0;
     }
     vrt::KArgs a;
-    std::memset(a.views, 0, sizeof a.views);
+    vrt::ViewSet vs;
+    std::memset(&vs, 0, sizeof vs);
     a.n_views = n_views;
     for (int i = 0; i < n_views; ++i) {
-        vrt::View &w = a.views[i];
+        vrt::View &w = vs.v[i];
         std::memcpy(w.inv_proj, views ? views[i].inv_projection : c->inv_proj, sizeof w.inv_proj);
         std::memcpy(w.inv_view, views ? views[i].inv_view : c->inv_view, sizeof w.inv_view);
         std::memcpy(w.cam_pos, views ? views[i].camera_pos : c->cam_pos, sizeof w.cam_pos);
@@ -260,36 +257,14 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     const bool prof = c->profiling && (c->prof_seen++ % c->prof_stride) == 0 && (c->prof_count + 1) * 2 <= c->prof_events.size();
     if (prof) VRT_HIP(c, hipEventRecord(c->prof_events[2 * c->prof_count], s));
     hipError_t e;
-    const bool default_shape = v.trav == 3 && !v.use_lds && v.tw == 8 && v.block == 256 && v.blocks_per_cu == 0;
-    if (n_views > 1 && default_shape && (mode == VRT_MODE_FULL || v.wpe == 6)) {
-        // several views in one launch: instantiated for the default traversal
-        if (mode == VRT_MODE_FULL) e = launch_one<2, vrt::v3::Trav, 8, 256, 1, false, true>(a, (int)grid, 0, s);
-        else if (mode == VRT_MODE_PRIMARY) e = launch_one<0, vrt::v3::Trav, 8, 256, 6, false, true>(a, (int)grid, 0, s);
-        else e = launch_one<1, vrt::v3::Trav, 8, 256, 6, false, true>(a, (int)grid, 0, s);
-    } else if (n_views > 1) {
-        // any other variant or a scene the wide layout cannot express: one launch per view, same pixels
-        if (prof) {  // the bracket below would straddle the recursion: close it around the whole group instead
-            for (int i = 0; i < n_views; ++i) {
-                const int r = enqueue_one_view(c, width, height, row0, n_rows, tile_rows, row_stride, compact, mode, s, views[i]);
-                if (r) return r;
-            }
-            VRT_HIP(c, hipEventRecord(c->prof_events[2 * c->prof_count + 1], s));
-            ++c->prof_count;
-            return VRT_OK;
-        }
-        for (int i = 0; i < n_views; ++i) {
-            const int r = enqueue_one_view(c, width, height, row0, n_rows, tile_rows, row_stride, compact, mode, s, views[i]);
-            if (r) return r;
-        }
-        return VRT_OK;
-    } else if (mode == VRT_MODE_FULL) {
+    if (mode == VRT_MODE_FULL) {
         // the full path tracer is instantiated for the default traversal and for the explicit-AABB baseline only
-        if (v.trav == 3) e = launch_one<2, vrt::v3::Trav, 8, 256, 1>(a, (int)grid, 0, s);
-        else if (v.trav == 2) e = launch_one<2, vrt::v2::Trav<false>, 8, 256, 1>(a, (int)grid, 0, s);
-        else e = launch_one<2, vrt::v1::Trav<false>, 8, 256, 1>(a, (int)grid, 0, s);
+        if (v.trav == 3) e = launch_one<2, vrt::v3::Trav, 8, 256, 1>(a, vs, (int)grid, 0, s);
+        else if (v.trav == 2) e = launch_one<2, vrt::v2::Trav<false>, 8, 256, 1>(a, vs, (int)grid, 0, s);
+        else e = launch_one<2, vrt::v1::Trav<false>, 8, 256, 1>(a, vs, (int)grid, 0, s);
     } else {
-        e = (mode == VRT_MODE_PRIMARY) ? launch_mode<0>(v, a, (int)grid, lds_bytes, s)
-                                       : launch_mode<1>(v, a, (int)grid, lds_bytes, s);
+        e = (mode == VRT_MODE_PRIMARY) ? launch_mode<0>(v, a, vs, (int)grid, lds_bytes, s)
+                                       : launch_mode<1>(v, a, vs, (int)grid, lds_bytes, s);
     }
     if (e != hipSuccess) return fail(c, VRT_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     if (prof) {
@@ -298,15 +273,6 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     }
     c->info.lds_records = a.lds_records;
     return VRT_OK;
-}
-
-int enqueue_one_view(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_rows, int row_stride, int compact,
-                     int mode, hipStream_t s, const vrt_view &view) {
-    const bool was = c->profiling;
-    c->profiling = false;  // the caller brackets the group
-    const int r = enqueue(c, width, height, row0, n_rows, tile_rows, row_stride, compact, mode, nullptr, nullptr, s, &view, 1);
-    c->profiling = was;
-    return r;
 }
 
 int check_frame(vrt_ctx *c, int width, int height) {
