@@ -27,6 +27,7 @@ POSES = {  # framing poses of SURVEY.md 8(d): x, y, z, yaw, pitch
     "terrain": (512.5, 420.5, 1000.5, -90.0, -20.0),  # config 4: procedural 1024^2 heightfield shell
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+PROFILE_EVERY = int(os.environ.get("VRT_BENCH_PROFILE_EVERY", "8"))  # every n-th launch of the timed region carries events
 
 
 def metric_name():
@@ -185,7 +186,7 @@ def main():
     fence()
     # every 8th launch of the timed region carries a hipEvent pair on its stream (a pair around EVERY launch keeps
     # consecutive launches from overlapping and costs ~6 % of the frame rate)
-    ctx.set_profiling(0 if args.no_kernel_events else args.steps, every=8)
+    ctx.set_profiling(0 if args.no_kernel_events else args.steps, every=PROFILE_EVERY)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

@@ -3,6 +3,7 @@
 #include "../../include/vrt.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdio>
@@ -109,7 +110,10 @@ int fail(vrt_ctx *c, int code, const std::string &msg) {
     } while (0)
 
 template <int MODE, class TRAV, int TW, int BLOCK, int WPE, bool PERSIST = false>
-hipError_t launch_one(const vrt::KArgs &a, const vrt::ViewSet &vs, int grid, size_t lds_bytes, hipStream_t s) {  // grid.y = a.n_views
+// ev0/ev1 (both or neither): events attached to THIS dispatch packet (hipExtLaunchKernel), so their elapsed time is
+// the kernel's own begin-to-end time, as a profiler reports it, without the latency of separate event markers
+hipError_t launch_one(const vrt::KArgs &a, const vrt::ViewSet &vs, int grid, size_t lds_bytes, hipStream_t s,
+                      hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {  // grid.y = a.n_views
     if (lds_bytes > 48 * 1024) {  // above the default dynamic-LDS ceiling: opt in (CDNA4 has 160 KiB per CU)
         static bool raised = false;
         if (!raised) {
@@ -119,13 +123,18 @@ hipError_t launch_one(const vrt::KArgs &a, const vrt::ViewSet &vs, int grid, siz
             raised = true;
         }
     }
-    hipLaunchKernelGGL((vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST>), dim3(grid, a.n_views), dim3(BLOCK), lds_bytes, s, a, vs);
+    if (ev0)
+        hipExtLaunchKernelGGL((vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST>), dim3(grid, a.n_views), dim3(BLOCK), lds_bytes, s,
+                              ev0, ev1, 0, a, vs);
+    else
+        hipLaunchKernelGGL((vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST>), dim3(grid, a.n_views), dim3(BLOCK), lds_bytes, s, a, vs);
     return hipGetLastError();
 }
 
 // The instantiated (traversal, LDS prefix, tile width, workgroup size, waves-per-SIMD) combinations.
 template <int MODE>
-hipError_t launch_mode(const Variant &v, const vrt::KArgs &a, const vrt::ViewSet &vs, int grid, size_t lds, hipStream_t s) {
+hipError_t launch_mode(const Variant &v, const vrt::KArgs &a, const vrt::ViewSet &vs, int grid, size_t lds, hipStream_t s,
+                       hipEvent_t ev0, hipEvent_t ev1) {
     using V1 = vrt::v1::Trav<false>;
     using V1L = vrt::v1::Trav<true>;
     using V2 = vrt::v2::Trav<false>;
@@ -133,29 +142,29 @@ hipError_t launch_mode(const Variant &v, const vrt::KArgs &a, const vrt::ViewSet
     using V3 = vrt::v3::Trav;
     if (v.blocks_per_cu > 0) {  // the persistent (grid-stride) form exists for one combination
         if (v.trav == 2 && !v.use_lds && v.tw == 8 && v.block == 256 && v.wpe == 1)
-            return launch_one<MODE, V2, 8, 256, 1, true>(a, vs, grid, lds, s);
+            return launch_one<MODE, V2, 8, 256, 1, true>(a, vs, grid, lds, s, ev0, ev1);
         return hipErrorInvalidValue;
     }
     const int key = v.trav * 1000000 + (v.use_lds ? 100000 : 0) + v.tw * 1000 + (v.block / 64) * 10 + v.wpe;
     switch (key) {
-        case 1000000 + 8000 + 40 + 1: return launch_one<MODE, V1, 8, 256, 1>(a, vs, grid, lds, s);
-        case 1100000 + 8000 + 40 + 1: return launch_one<MODE, V1L, 8, 256, 1>(a, vs, grid, lds, s);
-        case 2000000 + 8000 + 40 + 1: return launch_one<MODE, V2, 8, 256, 1>(a, vs, grid, lds, s);
-        case 2000000 + 8000 + 40 + 5: return launch_one<MODE, V2, 8, 256, 5>(a, vs, grid, lds, s);
-        case 2000000 + 8000 + 40 + 6: return launch_one<MODE, V2, 8, 256, 6>(a, vs, grid, lds, s);
-        case 2000000 + 8000 + 40 + 8: return launch_one<MODE, V2, 8, 256, 8>(a, vs, grid, lds, s);
-        case 2000000 + 16000 + 40 + 1: return launch_one<MODE, V2, 16, 256, 1>(a, vs, grid, lds, s);
-        case 2000000 + 8000 + 80 + 1: return launch_one<MODE, V2, 8, 512, 1>(a, vs, grid, lds, s);
-        case 2000000 + 8000 + 10 + 1: return launch_one<MODE, V2, 8, 64, 1>(a, vs, grid, lds, s);
-        case 2000000 + 8000 + 20 + 1: return launch_one<MODE, V2, 8, 128, 1>(a, vs, grid, lds, s);
-        case 2100000 + 8000 + 40 + 1: return launch_one<MODE, V2L, 8, 256, 1>(a, vs, grid, lds, s);
-        case 2100000 + 8000 + 160 + 1: return launch_one<MODE, V2L, 8, 1024, 1>(a, vs, grid, lds, s);
-        case 3000000 + 8000 + 40 + 1: return launch_one<MODE, V3, 8, 256, 1>(a, vs, grid, lds, s);
-        case 3000000 + 8000 + 40 + 6: return launch_one<MODE, V3, 8, 256, 6>(a, vs, grid, lds, s);
-        case 3000000 + 8000 + 40 + 8: return launch_one<MODE, V3, 8, 256, 8>(a, vs, grid, lds, s);
-        case 3000000 + 8000 + 10 + 1: return launch_one<MODE, V3, 8, 64, 1>(a, vs, grid, lds, s);
-        case 3000000 + 8000 + 10 + 8: return launch_one<MODE, V3, 8, 64, 8>(a, vs, grid, lds, s);
-        case 3000000 + 16000 + 40 + 1: return launch_one<MODE, V3, 16, 256, 1>(a, vs, grid, lds, s);
+        case 1000000 + 8000 + 40 + 1: return launch_one<MODE, V1, 8, 256, 1>(a, vs, grid, lds, s, ev0, ev1);
+        case 1100000 + 8000 + 40 + 1: return launch_one<MODE, V1L, 8, 256, 1>(a, vs, grid, lds, s, ev0, ev1);
+        case 2000000 + 8000 + 40 + 1: return launch_one<MODE, V2, 8, 256, 1>(a, vs, grid, lds, s, ev0, ev1);
+        case 2000000 + 8000 + 40 + 5: return launch_one<MODE, V2, 8, 256, 5>(a, vs, grid, lds, s, ev0, ev1);
+        case 2000000 + 8000 + 40 + 6: return launch_one<MODE, V2, 8, 256, 6>(a, vs, grid, lds, s, ev0, ev1);
+        case 2000000 + 8000 + 40 + 8: return launch_one<MODE, V2, 8, 256, 8>(a, vs, grid, lds, s, ev0, ev1);
+        case 2000000 + 16000 + 40 + 1: return launch_one<MODE, V2, 16, 256, 1>(a, vs, grid, lds, s, ev0, ev1);
+        case 2000000 + 8000 + 80 + 1: return launch_one<MODE, V2, 8, 512, 1>(a, vs, grid, lds, s, ev0, ev1);
+        case 2000000 + 8000 + 10 + 1: return launch_one<MODE, V2, 8, 64, 1>(a, vs, grid, lds, s, ev0, ev1);
+        case 2000000 + 8000 + 20 + 1: return launch_one<MODE, V2, 8, 128, 1>(a, vs, grid, lds, s, ev0, ev1);
+        case 2100000 + 8000 + 40 + 1: return launch_one<MODE, V2L, 8, 256, 1>(a, vs, grid, lds, s, ev0, ev1);
+        case 2100000 + 8000 + 160 + 1: return launch_one<MODE, V2L, 8, 1024, 1>(a, vs, grid, lds, s, ev0, ev1);
+        case 3000000 + 8000 + 40 + 1: return launch_one<MODE, V3, 8, 256, 1>(a, vs, grid, lds, s, ev0, ev1);
+        case 3000000 + 8000 + 40 + 6: return launch_one<MODE, V3, 8, 256, 6>(a, vs, grid, lds, s, ev0, ev1);
+        case 3000000 + 8000 + 40 + 8: return launch_one<MODE, V3, 8, 256, 8>(a, vs, grid, lds, s, ev0, ev1);
+        case 3000000 + 8000 + 10 + 1: return launch_one<MODE, V3, 8, 64, 1>(a, vs, grid, lds, s, ev0, ev1);
+        case 3000000 + 8000 + 10 + 8: return launch_one<MODE, V3, 8, 64, 8>(a, vs, grid, lds, s, ev0, ev1);
+        case 3000000 + 16000 + 40 + 1: return launch_one<MODE, V3, 16, 256, 1>(a, vs, grid, lds, s, ev0, ev1);
         default: return hipErrorInvalidValue;
     }
 }
@@ -255,22 +264,20 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     if (grid < 1) grid = 1;
     const size_t lds_bytes = (size_t)a.lds_records * sizeof(uint2);
     const bool prof = c->profiling && (c->prof_seen++ % c->prof_stride) == 0 && (c->prof_count + 1) * 2 <= c->prof_events.size();
-    if (prof) VRT_HIP(c, hipEventRecord(c->prof_events[2 * c->prof_count], s));
+    const hipEvent_t ev0 = prof ? c->prof_events[2 * c->prof_count] : nullptr;
+    const hipEvent_t ev1 = prof ? c->prof_events[2 * c->prof_count + 1] : nullptr;
     hipError_t e;
     if (mode == VRT_MODE_FULL) {
         // the full path tracer is instantiated for the default traversal and for the explicit-AABB baseline only
-        if (v.trav == 3) e = launch_one<2, vrt::v3::Trav, 8, 256, 1>(a, vs, (int)grid, 0, s);
+        if (v.trav == 3) e = launch_one<2, vrt::v3::Trav, 8, 256, 1>(a, vs, (int)grid, 0, s, ev0, ev1);
         else if (v.trav == 2) e = launch_one<2, vrt::v2::Trav<false>, 8, 256, 1>(a, vs, (int)grid, 0, s);
         else e = launch_one<2, vrt::v1::Trav<false>, 8, 256, 1>(a, vs, (int)grid, 0, s);
     } else {
-        e = (mode == VRT_MODE_PRIMARY) ? launch_mode<0>(v, a, vs, (int)grid, lds_bytes, s)
-                                       : launch_mode<1>(v, a, vs, (int)grid, lds_bytes, s);
+        e = (mode == VRT_MODE_PRIMARY) ? launch_mode<0>(v, a, vs, (int)grid, lds_bytes, s, ev0, ev1)
+                                       : launch_mode<1>(v, a, vs, (int)grid, lds_bytes, s, ev0, ev1);
     }
     if (e != hipSuccess) return fail(c, VRT_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-    if (prof) {
-        VRT_HIP(c, hipEventRecord(c->prof_events[2 * c->prof_count + 1], s));
-        ++c->prof_count;
-    }
+    if (prof) ++c->prof_count;
     c->info.lds_records = a.lds_records;
     return VRT_OK;
 }
