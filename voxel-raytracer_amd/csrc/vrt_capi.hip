@@ -383,7 +383,9 @@ int vrt_upload_octree(vrt_ctx *c, const uint8_t *texels, size_t used_bytes, uint
         VRT_HIP(c, hipMalloc((void **)&c->d_nodes, bytes));
         c->nodes_capacity = bytes;
     }
-    // stream-ordered after any dispatch still reading the old tree; synchronous so `lay` may die
+    // after every dispatch still reading the old tree, on whatever stream the caller enqueued it (uploads are rare:
+    // a device-wide wait is cheaper than a contract about foreign streams); synchronous so `lay` may die
+    VRT_HIP(c, hipDeviceSynchronize());
     VRT_HIP(c, hipMemcpyAsync(c->d_nodes, lay.records.data(), bytes, hipMemcpyHostToDevice, c->stream));
     VRT_HIP(c, hipStreamSynchronize(c->stream));
     c->info.tex_dim = tex_dim;
@@ -443,6 +445,7 @@ int vrt_upload_records(vrt_ctx *c, const uint32_t *records, size_t n_records, ui
         VRT_HIP(c, hipMalloc((void **)&c->d_nodes, bytes));
         c->nodes_capacity = bytes;
     }
+    VRT_HIP(c, hipDeviceSynchronize());  // see vrt_upload_octree
     VRT_HIP(c, hipMemcpyAsync(c->d_nodes, recs.data(), bytes, hipMemcpyHostToDevice, c->stream));
     VRT_HIP(c, hipStreamSynchronize(c->stream));
     c->info.tex_dim = tex_dim;
