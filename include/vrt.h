@@ -80,6 +80,25 @@ int vrt_set_params(vrt_ctx *ctx, const vrt_params *p);
 int vrt_upload_octree(vrt_ctx *ctx, const uint8_t *texels, size_t used_bytes, uint32_t tex_dim);
 int vrt_get_scene_info(const vrt_ctx *ctx, vrt_scene_info *info);
 
+/* EXTENSION: edits without re-flattening and re-uploading the tree (the reference does both on every build / destroy
+ * click, src/main.cpp:903-914). After the host octree has been edited at voxel (x, y, z):
+ *   1. vrt_patch_plan() names the deepest ancestor A of the voxel (depth <= max_depth) whose sub-tree can be replaced
+ *      on the device: depth below the root and the child index taken at each level;
+ *   2. the host library says whether A is still an internal node (vrth_octree_node_state) -- if not, plan again with
+ *      max_depth = depth - 1 -- and emits A's new sub-tree (vrth_octree_subtree_records);
+ *   3. vrt_patch_apply() appends those records, rewrites A's record, rebuilds A's part of the wide layout and copies
+ *      only what changed to the device (after waiting for dispatches in flight).
+ * vrt_patch_plan returns VRT_E_STATE when no ancestor qualifies (use vrt_upload_octree / vrt_upload_records).
+ * Replaced sub-trees stay allocated until the next full upload; vrt_get_scene_info().n_records grows accordingly.
+ * Pixels after a patch equal those after a full upload of the edited tree. */
+typedef struct vrt_patch {
+    int32_t depth;       /* of A below the root, >= 1 */
+    uint8_t path[16];    /* child index taken at levels 0 .. depth-1 */
+} vrt_patch;
+int vrt_patch_plan(vrt_ctx *ctx, int x, int y, int z, int max_depth, vrt_patch *out);
+int vrt_patch_apply(vrt_ctx *ctx, const vrt_patch *patch, const uint32_t *subtree_records, size_t n_records);
+
+
 /* EXTENSION (not a reference interface): upload the device record array itself -- 2 x uint32 per record,
  * level order, root first; internal: {child_mask | leaf_mask << 8, first child index}, leaf:
  * {R | G<<8 | B<<16 | alpha<<24, refr | illum<<8 | k<<16} -- as vrth_world_records() (vrt_host.h) emits it

@@ -51,6 +51,14 @@ int vrth_world_flatten(vrth_world *w, uint8_t **texels, size_t *bytes, uint32_t 
 int vrth_world_records(vrth_world *w, uint32_t **records, size_t *n_records, uint32_t *tex_dim);
 /* the same for a caller that holds the Octree* itself (octree.hpp) */
 int vrth_octree_records(void *octree_root, uint32_t **records, size_t *n_records, uint32_t *tex_dim);
+/* EXTENSION, for vrt_patch_plan / vrt_patch_apply (vrt.h): the node reached from the root by `depth` child indices
+ * (child i = (x >= mid) * 4 + (y >= mid) * 2 + (z >= mid), src/octree.cpp:46-76) as the flattening sees it --
+ * 0 absent, 1 leaf, 2 internal -- and, for an internal node, its sub-tree as device records (that node = record 0,
+ * child indices local to the sub-tree; vrth_free). */
+int vrth_octree_node_state(void *octree_root, const uint8_t *path, int depth);
+int vrth_octree_subtree_records(void *octree_root, const uint8_t *path, int depth, uint32_t **records, size_t *n_records);
+int vrth_world_node_state(vrth_world *w, const uint8_t *path, int depth);
+int vrth_world_subtree_records(vrth_world *w, const uint8_t *path, int depth, uint32_t **records, size_t *n_records);
 void vrth_free(void *p);
 
 /* Camera(position, up=(0,1,0), yaw, pitch) -> the dispatch's Camera block for a width x height frame;

@@ -603,3 +603,107 @@ def test_views_in_one_launch_equal_separate_dispatches(ctx, V, product_scenes):
             ctx.set_variant(0)
     with pytest.raises(V.VrtError):
         ctx.dispatch_views(W, H, 8, 0, 1, 0, [cams[0] + (0, 0)] * 5)
+
+
+def test_voxel_edits_patched_on_device_equal_full_uploads(V, O):
+    """vrt_patch_plan / vrt_patch_apply: after every build / destroy edit of the host octree, the context patched in
+    place renders the frames of a context that received a full upload of the edited tree (wide, bit-indexed and
+    explicit-AABB kernels; the display of the eye's medium reads the record array) and the oracle's."""
+    rng = np.random.default_rng(77)
+    w = V.World()
+    assert w.load_vox(os.path.join(MAPS, "dragon.vox"))
+    a, b = V.Context(0), V.Context(0)
+    a.upload_octree(*w.flatten())
+    W, H = 160, 90
+    poses = [(63.5, 60.5, 140.5, -90.0, -10.0), (30.5, 70.5, 20.5, 45.0, -35.0)]
+    cams = [V.camera_block(p[:3], p[3], p[4], W, H)[:3] for p in poses]
+    patched = full = 0
+    existing = []
+    for step in range(60):
+        kind = step % 6
+        if kind in (0, 1):        # destroy something visible from a random direction
+            d = rng.normal(size=3)
+            d /= np.linalg.norm(d)
+            hit = w.ray_cast(tuple(np.array([63.0, 45.0, 28.0]) - d * 150.0), tuple(d))
+            if not hit or not hit[1]:
+                continue
+            x, y, z = hit[0]
+            w.remove(x, y, z)
+        elif kind == 2 and existing:   # destroy something built earlier
+            x, y, z = existing.pop(int(rng.integers(0, len(existing))))
+            w.remove(x, y, z)
+        elif kind == 3:            # build far from everything (new branches near the top of the tree)
+            x, y, z = (int(v) for v in rng.integers(0, 1000, size=3))
+            w.insert(x, y, z, 0xffd2d2ff, 3.0, 1.0, 0.0)
+            existing.append((x, y, z))
+        elif kind == 4:            # build outside the octant that holds the wide layout
+            x, y, z = (int(v) for v in rng.integers(-900, -1, size=3))
+            w.insert(x, y, z, 0x50b43cff)
+            existing.append((x, y, z))
+        else:                      # build next to the model: glass, water, stone
+            x, y, z = int(rng.integers(0, 126)), int(rng.integers(0, 95)), int(rng.integers(0, 60))
+            m = [(0xc8dcff50, 1.5, 0.0, 0.0), (0x3c64dc96, 1.33, 0.0, 0.02), (0xa0a0a0ff, 3.0, 0.0, 0.0)][step % 3]
+            w.insert(x, y, z, *m)
+            existing.append((x, y, z))
+        depth = a.patch_voxel(w, x, y, z)
+        if depth is None:
+            a.upload_octree(*w.flatten())
+            full += 1
+        else:
+            patched += 1
+        if step % 5 == 4 or step == 59:
+            tex, dim = w.flatten()
+            b.upload_octree(tex, dim)
+            info = a.scene_info()                       # the patches kept the stream's size and u_texDim current
+            assert (info["n_texels"], info["tex_dim"]) == (len(tex) // 4, dim), (step, info, len(tex) // 4, dim)
+            for ci, cam in enumerate(cams):
+                for variant in (0, 4, 1):
+                    for mode in ((0, 1, 2) if variant == 0 else (1,)):
+                        frames = []
+                        for ctx_ in (a, b):
+                            ctx_.set_variant(variant)
+                            ctx_.set_camera(*cam)
+                            ctx_.set_params(ctx_.default_params())
+                            frames.append(ctx_.dispatch(W, H, mode))
+                        what = f"edit {step} pose {ci} variant {variant} mode {mode}"
+                        _assert_same(frames[0][0], frames[1][0], what + " rgba8 (patched vs full upload)")
+                        _assert_same(frames[0][1], frames[1][1], what + " id/dist (patched vs full upload)")
+                        if variant == 0 and mode == 1:
+                            ref_rgba, ref_id, _ = _oracle_frame(O, tex, dim, cam, W, H, mode)
+                            _assert_same(frames[0][0], ref_rgba, what + " rgba8 vs oracle")
+                            _assert_same(frames[0][1], ref_id, what + " id/dist vs oracle")
+    assert patched >= 25 and full >= 5, (patched, full)       # both routes were exercised
+    grown = a.scene_info()["n_records"] - b.scene_info()["n_records"]
+    assert 0 < grown < 60 * 400, grown          # replaced child blocks stay behind, but only the ones along each path
+    # a long session on a small world: the garbage bound makes the plan ask for a full upload now and then
+    w2 = V.World()
+    for x in range(8):
+        for z in range(8):
+            w2.insert(x, 0, z, 0xa0a0a0ff)
+    a.upload_octree(*w2.flatten())
+    refused = 0
+    for step in range(4000):
+        x, y, z = (int(v) for v in rng.integers(0, 24, size=3))
+        if step % 3 == 2:
+            w2.remove(x, y, z)
+        else:
+            w2.insert(x, y, z, 0x50b43cff if step % 2 else 0xc8dcff50, 1.5 if step % 2 == 0 else 3.0, 0.0, 0.0)
+        if a.patch_voxel(w2, x, y, z) is None:
+            refused += 1
+            a.upload_octree(*w2.flatten())
+    assert refused >= 1
+    tex, dim = w2.flatten()
+    b.upload_octree(tex, dim)
+    info = a.scene_info()
+    assert (info["n_texels"], info["tex_dim"]) == (len(tex) // 4, dim), (info, len(tex) // 4, dim)
+    cam = V.camera_block((12.5, 30.5, 60.5), -90.0, -25.0, W, H)[:3]
+    for ctx_ in (a, b):
+        ctx_.set_variant(0)
+        ctx_.set_camera(*cam)
+        ctx_.set_params(ctx_.default_params())
+    for mode in (0, 1, 2):
+        fa, fb = a.dispatch(W, H, mode), b.dispatch(W, H, mode)
+        _assert_same(fa[0], fb[0], f"long session mode {mode} rgba8")
+        _assert_same(fa[1], fb[1], f"long session mode {mode} id/dist")
+    a.close()
+    b.close()

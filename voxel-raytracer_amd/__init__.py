@@ -44,6 +44,11 @@ class View(C.Structure):
                 ("d_rgba8", C.c_void_p), ("d_id_dist", C.c_void_p)]
 
 
+class Patch(C.Structure):
+    """vrt_patch: an ancestor of an edited voxel, by depth and child-index path"""
+    _fields_ = [("depth", C.c_int32), ("path", C.c_uint8 * 16)]
+
+
 class SceneInfo(C.Structure):
     _fields_ = [("tex_dim", C.c_uint32), ("n_texels", C.c_uint32), ("n_records", C.c_uint32),
                 ("n_internal", C.c_uint32), ("n_leaves", C.c_uint32), ("max_depth", C.c_uint32),
@@ -131,6 +136,8 @@ def hip_lib():
         L.vrt_debug_set_denoise_variant.argtypes = [C.c_void_p, C.c_int]
         L.vrt_dispatch_views.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(View), C.c_int, C.c_void_p]
+        L.vrt_patch_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Patch)]
+        L.vrt_patch_apply.argtypes = [C.c_void_p, C.POINTER(Patch), C.c_void_p, C.c_size_t]
         L.vrt_dispatch_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vrt_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.vrt_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
@@ -408,6 +415,30 @@ class Context:
         out = np.zeros_like(rgba)
         self._chk(self._L.vrt_denoise_host(self._h, w, h, rgba.ctypes.data, idd.ctypes.data, out.ctypes.data))
         return out
+
+    def patch_voxel(self, world, x, y, z, max_depth=15):
+        """After `world` has been edited at voxel (x, y, z): replaces the smallest enclosing sub-tree on the device
+        (vrt_patch_plan / vrth_world_subtree_records / vrt_patch_apply). Returns the depth of the node replaced, or None
+        when the edit needs a full upload (nothing was changed on the device then)."""
+        H = host_lib()
+        H.vrth_world_node_state.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int]
+        H.vrth_world_subtree_records.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_void_p),
+                                                 C.POINTER(C.c_size_t)]
+        plan = Patch()
+        while max_depth >= 1:
+            if self._L.vrt_patch_plan(self._h, x, y, z, max_depth, C.byref(plan)) != 0:
+                return None
+            if H.vrth_world_node_state(world._h, plan.path, plan.depth) == 2:
+                p, n = C.c_void_p(), C.c_size_t(0)
+                if H.vrth_world_subtree_records(world._h, plan.path, plan.depth, C.byref(p), C.byref(n)) != 0:
+                    return None
+                try:
+                    self._chk(self._L.vrt_patch_apply(self._h, C.byref(plan), p, n.value))
+                finally:
+                    H.vrth_free(p)
+                return plan.depth
+            max_depth = plan.depth - 1
+        return None
 
     def dispatch_views(self, width, height, tile_rows, shard, n_shards, mode, views, stream=None):
         """views: sequence of (inv_proj, inv_view, cam_pos, d_rgba8, d_id_dist) or a prepared (View * n) array;

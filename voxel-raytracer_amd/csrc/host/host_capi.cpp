@@ -164,26 +164,23 @@ int vrth_world_records(vrth_world *w, uint32_t **records, size_t *n_records, uin
     return vrth_octree_records(w->root, records, n_records, tex_dim);
 }
 
-// the same for a C++ caller that holds the Octree* itself (the reference's chunk0)
-int vrth_octree_records(void *octree_root, uint32_t **records, size_t *n_records, uint32_t *tex_dim) {
-    if (!octree_root || !records || !n_records || !tex_dim) return -1;
-    Octree *root = static_cast<Octree *>(octree_root);
-    const size_t texels = _octree_texel_size(root);
-    size_t d = (size_t)ceil(cbrt((double)texels));
-    *tex_dim = (uint32_t)(d == 0 ? 1 : d);
-    if (!root->children && root->has_voxel) return -2;
+namespace {
+// a child the flattening counts (src/octree.cpp:524-545): it holds a voxel or has a children array
+inline bool counted(const Octree *c) { return c && (c->has_voxel || c->children); }
+
+// Records of the sub-tree under `top` in level order, top = record 0 (child indices local to the sub-tree);
+// `top_depth` = depth of `top` below the root, for the 16-iteration truncation of the shader's descent.
+void emit_records(const Octree *top, uint32_t top_depth, std::vector<uint32_t> &out) {
     struct Item { const Octree *n; uint32_t rec, depth; };
-    std::vector<uint32_t> out(2, 0u);
+    out.assign(2, 0u);
     std::vector<Item> queue;
-    queue.push_back(Item{root, 0u, 0u});
+    queue.push_back(Item{top, 0u, top_depth});
     for (size_t head = 0; head < queue.size(); ++head) {
         const Item it = queue[head];
         uint32_t mask = 0, leaf_mask = 0;
         if (it.n->children && it.depth < 15)
-            for (int i = 0; i < 8; ++i) {
-                const Octree *c = it.n->children[i];
-                if (c && (c->has_voxel || c->children)) mask |= 1u << i;
-            }
+            for (int i = 0; i < 8; ++i)
+                if (counted(it.n->children[i])) mask |= 1u << i;
         const uint32_t first = (uint32_t)(out.size() / 2);
         for (int i = 0; i < 8; ++i) {
             if (!(mask & (1u << i))) continue;
@@ -208,11 +205,66 @@ int vrth_octree_records(void *octree_root, uint32_t **records, size_t *n_records
         out[2 * (size_t)it.rec] = mask | (leaf_mask << 8);
         out[2 * (size_t)it.rec + 1] = first;
     }
+}
+
+int hand_over(const std::vector<uint32_t> &out, uint32_t **records, size_t *n_records) {
     *n_records = out.size() / 2;
     *records = (uint32_t *)malloc(out.size() * sizeof(uint32_t));
     if (!*records) return -1;
     memcpy(*records, out.data(), out.size() * sizeof(uint32_t));
     return 0;
+}
+
+// the node reached from the root by `depth` child indices, or NULL when the flattening would not reach it
+const Octree *walk(const Octree *root, const uint8_t *path, int depth) {
+    const Octree *n = root;
+    for (int d = 0; d < depth; ++d) {
+        if (!n->children || path[d] > 7 || d >= 15) return nullptr;
+        const Octree *c = n->children[path[d]];
+        if (!counted(c)) return nullptr;
+        n = c;
+    }
+    return n;
+}
+}  // namespace
+
+// the same for a C++ caller that holds the Octree* itself (the reference's chunk0)
+int vrth_octree_records(void *octree_root, uint32_t **records, size_t *n_records, uint32_t *tex_dim) {
+    if (!octree_root || !records || !n_records || !tex_dim) return -1;
+    Octree *root = static_cast<Octree *>(octree_root);
+    const size_t texels = _octree_texel_size(root);
+    size_t d = (size_t)ceil(cbrt((double)texels));
+    *tex_dim = (uint32_t)(d == 0 ? 1 : d);
+    if (!root->children && root->has_voxel) return -2;
+    std::vector<uint32_t> out;
+    emit_records(root, 0u, out);
+    return hand_over(out, records, n_records);
+}
+
+// 0: the flattened tree has no node there, 1: a leaf, 2: an internal node
+int vrth_octree_node_state(void *octree_root, const uint8_t *path, int depth) {
+    if (!octree_root || (!path && depth > 0) || depth < 0 || depth > 15) return -1;
+    const Octree *n = walk(static_cast<const Octree *>(octree_root), path, depth);
+    if (!n) return 0;
+    if (!n->children) return n->has_voxel ? 1 : 0;
+    return 2;
+}
+
+int vrth_octree_subtree_records(void *octree_root, const uint8_t *path, int depth, uint32_t **records, size_t *n_records) {
+    if (!octree_root || (!path && depth > 0) || depth < 0 || depth > 15 || !records || !n_records) return -1;
+    const Octree *n = walk(static_cast<const Octree *>(octree_root), path, depth);
+    if (!n || !n->children) return -2;
+    std::vector<uint32_t> out;
+    emit_records(n, (uint32_t)depth, out);
+    return hand_over(out, records, n_records);
+}
+
+int vrth_world_node_state(vrth_world *w, const uint8_t *path, int depth) {
+    return w ? vrth_octree_node_state(w->root, path, depth) : -1;
+}
+
+int vrth_world_subtree_records(vrth_world *w, const uint8_t *path, int depth, uint32_t **records, size_t *n_records) {
+    return w ? vrth_octree_subtree_records(w->root, path, depth, records, n_records) : -1;
 }
 
 void vrth_free(void *p) { free(p); }

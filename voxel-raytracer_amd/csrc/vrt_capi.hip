@@ -85,6 +85,9 @@ struct vrt_ctx {
     // host copy of the records: lets the dispatcher check the bit-indexed traversal's precondition
     // against the CURRENT world bounds (they arrive separately, through vrt_set_params)
     std::vector<vrt::Record> host_records;
+    size_t uploaded_records = 0;  // size of host_records after the last full upload (patches append to it)
+    size_t stream_texels = 0;     // texels of the reference's stream for the current tree (kept current by patches)
+    bool dim_from_texels = false; // the uploaded tex_dim was ceil(cbrt(texels)): patches keep it that way
     bool analysis_valid = false;
     bool unit_internal = false;
     // wide layout (vrt_layout.h), rebuilt whenever the tree or the world bounds change
@@ -170,6 +173,8 @@ hipError_t launch_mode(const Variant &v, const vrt::KArgs &a, const vrt::ViewSet
 }
 
 // Builds the kernel arguments for local rows [0, n_rows) and enqueues one launch.
+int ensure_analysis(vrt_ctx *c);
+
 // views == nullptr: one view, the context's camera (vrt_set_camera) rendering into d_rgba / d_id.
 int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_rows, int row_stride, int compact,
             int mode, void *d_rgba, void *d_id, hipStream_t s, const vrt_view *views = nullptr, int n_views = 1) {
@@ -179,28 +184,9 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     if (mode != VRT_MODE_PRIMARY && mode != VRT_MODE_PRIMARY_SHADOW && mode != VRT_MODE_FULL)
         return fail(c, VRT_E_INVALID, "unknown mode");
     if (n_rows <= 0) return VRT_OK;
-    if (!c->analysis_valid) {
-        // the world bounds decide which sub-trees are aligned cubes: (re)derive the layouts that depend on them
-        c->unit_internal = vrt::has_unit_internal_node(c->host_records, c->params.world_min, c->params.world_max);
-        std::string why;
-        c->wide_ok = !c->unit_internal &&
-                     vrt::build_wide(c->host_records, c->params.world_min, c->params.world_max, c->wide, why);
-        if (c->wide_ok) {
-            const size_t bytes = (c->wide.cells.empty() ? 64 : c->wide.cells.size()) * sizeof(vrt::WideCell);
-            if (bytes > c->cells_capacity) {
-                VRT_HIP(c, hipDeviceSynchronize());
-                if (c->d_cells) VRT_HIP(c, hipFree(c->d_cells));
-                c->d_cells = nullptr;
-                c->cells_capacity = 0;
-                VRT_HIP(c, hipMalloc((void **)&c->d_cells, bytes));
-                c->cells_capacity = bytes;
-            }
-            // rare (scene or bounds changed): a blocking copy keeps it ordered against any caller stream
-            VRT_HIP(c, hipDeviceSynchronize());
-            if (!c->wide.cells.empty())
-                VRT_HIP(c, hipMemcpy(c->d_cells, c->wide.cells.data(), c->wide.cells.size() * sizeof(vrt::WideCell), hipMemcpyHostToDevice));
-        }
-        c->analysis_valid = true;
+    {
+        const int ra = ensure_analysis(c);
+        if (ra) return ra;
     }
     Variant v = kVariants[c->variant];
     if (v.trav == 3 && !c->wide_ok) {  // wide layout not expressible for this scene: record-array kernels
@@ -365,6 +351,14 @@ int vrt_set_params(vrt_ctx *c, const vrt_params *p) {
     return VRT_OK;
 }
 
+namespace {
+// src/main.cpp:266-268: tex_dim = (size_t)ceil(cbrt((double)total_texels)), at least 1
+uint32_t dim_of_texels(size_t texels) {
+    const size_t d = (size_t)ceil(cbrt((double)texels));
+    return (uint32_t)(d == 0 ? 1 : d);
+}
+}  // namespace
+
 int vrt_upload_octree(vrt_ctx *c, const uint8_t *texels, size_t used_bytes, uint32_t tex_dim) {
     if (!c) return VRT_E_INVALID;
     if (used_bytes % 4 != 0) return fail(c, VRT_E_INVALID, "vrt_upload_octree: used_bytes must be a multiple of 4");
@@ -396,6 +390,9 @@ int vrt_upload_octree(vrt_ctx *c, const uint8_t *texels, size_t used_bytes, uint
     c->info.max_depth = lay.max_depth;
     c->info.lds_records = 0;
     c->host_records.swap(lay.records);
+    c->uploaded_records = c->host_records.size();
+    c->stream_texels = used_bytes / 4;
+    c->dim_from_texels = tex_dim == dim_of_texels(c->stream_texels);
     c->analysis_valid = false;
     c->have_scene = true;
     return VRT_OK;
@@ -456,8 +453,139 @@ int vrt_upload_records(vrt_ctx *c, const uint32_t *records, size_t n_records, ui
     c->info.max_depth = max_depth;
     c->info.lds_records = 0;
     c->host_records.swap(recs);
+    c->uploaded_records = c->host_records.size();
+    c->stream_texels = vrt::stream_texels(c->host_records.data(), c->host_records.size(), 0);
+    c->dim_from_texels = tex_dim == dim_of_texels(c->stream_texels);
     c->analysis_valid = false;
     c->have_scene = true;
+    return VRT_OK;
+}
+
+namespace {
+// (re)derives what depends on the world bounds: whether the wide layout can be used, and the layout itself on the
+// device. Called lazily by the dispatcher and by the patch entry points.
+int ensure_analysis(vrt_ctx *c) {
+    if (c->analysis_valid) return VRT_OK;
+    c->unit_internal = vrt::has_unit_internal_node(c->host_records, c->params.world_min, c->params.world_max);
+    std::string why;
+    c->wide_ok = !c->unit_internal &&
+                 vrt::build_wide(c->host_records, c->params.world_min, c->params.world_max, c->wide, why);
+    if (c->wide_ok) {
+        const size_t bytes = (c->wide.cells.empty() ? 64 : c->wide.cells.size()) * sizeof(vrt::WideCell);
+        if (bytes > c->cells_capacity) {
+            VRT_HIP(c, hipDeviceSynchronize());
+            if (c->d_cells) VRT_HIP(c, hipFree(c->d_cells));
+            c->d_cells = nullptr;
+            c->cells_capacity = 0;
+            VRT_HIP(c, hipMalloc((void **)&c->d_cells, bytes + bytes / 2));  // room for patches
+            c->cells_capacity = bytes + bytes / 2;
+        }
+        // rare (scene or bounds changed): a blocking copy keeps it ordered against any caller stream
+        VRT_HIP(c, hipDeviceSynchronize());
+        if (!c->wide.cells.empty())
+            VRT_HIP(c, hipMemcpy(c->d_cells, c->wide.cells.data(), c->wide.cells.size() * sizeof(vrt::WideCell), hipMemcpyHostToDevice));
+    }
+    c->analysis_valid = true;
+    return VRT_OK;
+}
+}  // namespace
+
+int vrt_patch_plan(vrt_ctx *c, int x, int y, int z, int max_depth, vrt_patch *out) {
+    if (!c || !out) return c ? fail(c, VRT_E_INVALID, "vrt_patch_plan: null output") : VRT_E_INVALID;
+    if (!c->have_scene) return fail(c, VRT_E_STATE, "vrt_patch_plan: no octree uploaded");
+    VRT_HIP(c, hipSetDevice(c->device));
+    int r = ensure_analysis(c);
+    if (r) return r;
+    // replaced sub-trees stay allocated: once they outweigh the tree several times over, ask for the full upload that
+    // compacts everything
+    if (c->host_records.size() > 4 * c->uploaded_records + (1u << 12))
+        return fail(c, VRT_E_STATE, "vrt_patch_plan: too much replaced data behind the tree (full upload needed)");
+    vrt::PatchSite site;
+    const int p[3] = {x, y, z};
+    if (!vrt::plan_patch(c->host_records, c->wide, c->wide_ok, c->params.world_min, c->params.world_max, p,
+                         max_depth > 15 ? 15 : max_depth, site))
+        return fail(c, VRT_E_STATE, "vrt_patch_plan: no patchable ancestor (full upload needed)");
+    out->depth = site.depth;
+    std::memcpy(out->path, site.path, sizeof out->path);
+    return VRT_OK;
+}
+
+int vrt_patch_apply(vrt_ctx *c, const vrt_patch *patch, const uint32_t *subtree_records, size_t n_records) {
+    if (!c || !patch || !subtree_records) return c ? fail(c, VRT_E_INVALID, "vrt_patch_apply: null argument") : VRT_E_INVALID;
+    if (!c->have_scene) return fail(c, VRT_E_STATE, "vrt_patch_apply: no octree uploaded");
+    if (patch->depth < 1 || patch->depth > 15) return fail(c, VRT_E_INVALID, "vrt_patch_apply: depth out of range");
+    VRT_HIP(c, hipSetDevice(c->device));
+    int r = ensure_analysis(c);
+    if (r) return r;
+    // find A again from the path (the plan carries no pointers into this context)
+    vrt::PatchSite site;
+    {
+        int lo[3], hi[3];
+        for (int k = 0; k < 3; ++k) { lo[k] = c->params.world_min[k]; hi[k] = c->params.world_max[k]; }
+        for (int d = 0; d < patch->depth; ++d) {
+            const uint32_t ci = patch->path[d];
+            if (ci > 7) return fail(c, VRT_E_INVALID, "vrt_patch_apply: bad path");
+            for (int k = 0; k < 3; ++k) {
+                const int mid = lo[k] + ((hi[k] - lo[k]) >> 1);
+                if ((ci >> (2 - k)) & 1u) lo[k] = mid; else hi[k] = mid;
+            }
+        }
+        if (!vrt::plan_patch(c->host_records, c->wide, c->wide_ok, c->params.world_min, c->params.world_max, lo, patch->depth, site) ||
+            site.depth != patch->depth || std::memcmp(site.path, patch->path, (size_t)patch->depth) != 0)
+            return fail(c, VRT_E_STATE, "vrt_patch_apply: the path does not name a patchable node of the uploaded tree");
+    }
+    const size_t texels_before = vrt::stream_texels(c->host_records.data(), c->host_records.size(), site.record);
+    const size_t texels_after = vrt::stream_texels(reinterpret_cast<const vrt::Record *>(subtree_records), n_records, 0);
+    vrt::PatchRanges rg;
+    std::string why;
+    if (!vrt::apply_patch(c->host_records, c->wide, c->wide_ok, site, reinterpret_cast<const vrt::Record *>(subtree_records),
+                          n_records, rg, why))
+        return fail(c, VRT_E_MALFORMED, "vrt_patch_apply: " + why);
+    // device copies, after every dispatch that may still read the old structures
+    VRT_HIP(c, hipDeviceSynchronize());
+    const size_t rec_bytes = c->host_records.size() * sizeof(vrt::Record);
+    if (rec_bytes > c->nodes_capacity) {
+        if (c->d_nodes) VRT_HIP(c, hipFree(c->d_nodes));
+        c->d_nodes = nullptr;
+        c->nodes_capacity = 0;
+        VRT_HIP(c, hipMalloc((void **)&c->d_nodes, rec_bytes * 2));
+        c->nodes_capacity = rec_bytes * 2;
+        VRT_HIP(c, hipMemcpy(c->d_nodes, c->host_records.data(), rec_bytes, hipMemcpyHostToDevice));
+    } else {
+        const size_t from = rg.records_appended_from;
+        if (c->host_records.size() > from)
+            VRT_HIP(c, hipMemcpy(c->d_nodes + from, c->host_records.data() + from, (c->host_records.size() - from) * sizeof(vrt::Record),
+                                 hipMemcpyHostToDevice));
+        VRT_HIP(c, hipMemcpy(c->d_nodes + site.record, c->host_records.data() + site.record, sizeof(vrt::Record), hipMemcpyHostToDevice));
+    }
+    c->info.n_records = (uint32_t)c->host_records.size();
+    c->stream_texels = c->stream_texels - texels_before + texels_after;
+    c->info.n_texels = (uint32_t)c->stream_texels;
+    if (c->dim_from_texels) c->info.tex_dim = dim_of_texels(c->stream_texels);  // what updateGPUTexture would pass now
+    if (c->wide_ok) {
+        if (rg.wide_invalid) {
+            c->analysis_valid = false;  // the next dispatch rebuilds the wide layout from the patched records
+        } else {
+            const size_t cell_bytes = c->wide.cells.size() * sizeof(vrt::WideCell);
+            if (cell_bytes > c->cells_capacity) {
+                if (c->d_cells) VRT_HIP(c, hipFree(c->d_cells));
+                c->d_cells = nullptr;
+                c->cells_capacity = 0;
+                VRT_HIP(c, hipMalloc((void **)&c->d_cells, cell_bytes * 2));
+                c->cells_capacity = cell_bytes * 2;
+                VRT_HIP(c, hipMemcpy(c->d_cells, c->wide.cells.data(), cell_bytes, hipMemcpyHostToDevice));
+            } else {
+                const size_t from = rg.cells_appended_from;
+                if (c->wide.cells.size() > from)
+                    VRT_HIP(c, hipMemcpy(c->d_cells + from, c->wide.cells.data() + from, (c->wide.cells.size() - from) * sizeof(vrt::WideCell),
+                                         hipMemcpyHostToDevice));
+                if (rg.cell_repointed) {
+                    const size_t at = (size_t)site.parent_node * 64 + site.parent_cell;
+                    VRT_HIP(c, hipMemcpy(c->d_cells + at, c->wide.cells.data() + at, sizeof(vrt::WideCell), hipMemcpyHostToDevice));
+                }
+            }
+        }
+    }
     return VRT_OK;
 }
 

@@ -1,6 +1,8 @@
 // vrt_layout.cpp -- see vrt_layout.h
 #include "vrt_layout.h"
 
+#include <cstring>
+
 #include <deque>
 
 namespace vrt {
@@ -119,9 +121,16 @@ inline uint32_t leaf_props(const Record &leaf) {
     return (leaf.w0 >> 24) != 0u ? w1 : (w1 & 0x00ffff00u);
 }
 
-bool build_wide_node(const std::vector<Record> &recs, uint32_t rec, int shift, WideTree &out, uint32_t &node, std::string &why) {
+// Reuse (patches): `old_node` >= 0 is the wide node that stood for this octree node before the edit. A grandchild
+// record with an index below `frozen_below` (and not `rewritten`, the one record a patch changes in place) is an
+// old, immutable record, so its whole sub-tree is unchanged: if the old wide node had a child built from that very
+// record, that child is kept instead of being rebuilt.
+bool build_wide_node(const std::vector<Record> &recs, uint32_t rec, int shift, WideTree &out, uint32_t &node, std::string &why,
+                     long old_node = -1, size_t frozen_below = 0, uint32_t rewritten = 0xffffffffu) {
     node = out.n_nodes++;
     out.cells.resize((size_t)out.n_nodes * 64, WideCell{0u, 0u});
+    out.node_record.resize(out.n_nodes, 0u);
+    out.node_record[node] = rec;
     for (uint32_t cell = 0; cell < 64; ++cell) {
         const uint32_t cx = (cell >> 4) & 3u, cy = (cell >> 2) & 3u, cz = cell & 3u;
         const uint32_t hi = ((cx >> 1) << 2) | ((cy >> 1) << 1) | (cz >> 1);
@@ -147,7 +156,16 @@ bool build_wide_node(const std::vector<Record> &recs, uint32_t rec, int shift, W
                     return false;
                 }
                 uint32_t child = 0;
-                if (!build_wide_node(recs, i2, shift - 2, out, child, why)) return false;
+                long old_child = -1;
+                if (old_node >= 0) {
+                    const WideCell oc = out.cells[(size_t)old_node * 64 + cell];
+                    if (oc.w1 == kWideInternal && oc.w0 < out.node_record.size()) old_child = (long)oc.w0;
+                }
+                if (old_child >= 0 && i2 < frozen_below && i2 != rewritten && out.node_record[(size_t)old_child] == i2) {
+                    child = (uint32_t)old_child;  // unchanged sub-tree: keep its wide nodes
+                } else if (!build_wide_node(recs, i2, shift - 2, out, child, why, old_child, frozen_below, rewritten)) {
+                    return false;
+                }
                 c.w0 = child;
                 c.w1 = kWideInternal;
             }
@@ -267,6 +285,189 @@ bool has_unit_internal_node(const std::vector<Record> &records, const int wmin[3
         }
     }
     return false;
+}
+
+size_t stream_texels(const Record *recs, size_t n, uint32_t top) {
+    if (top >= n) return 0;
+    size_t total = 0;
+    std::vector<uint32_t> todo(1, top);  // internal records still to count
+    while (!todo.empty()) {
+        const uint32_t r = todo.back();
+        todo.pop_back();
+        const uint32_t mask = recs[r].w0 & 0xffu, leaf_mask = (recs[r].w0 >> 8) & 0xffu;
+        const uint32_t n_child = (uint32_t)__builtin_popcount(mask);
+        total += 1 + n_child;
+        uint32_t rank = 0;
+        for (uint32_t ci = 0; ci < 8; ++ci) {
+            if (!((mask >> ci) & 1u)) continue;
+            const size_t idx = (size_t)recs[r].w1 + rank++;
+            if (idx >= n) continue;
+            if ((leaf_mask >> ci) & 1u) total += 2;
+            else todo.push_back((uint32_t)idx);
+        }
+    }
+    return total;
+}
+
+bool plan_patch(const std::vector<Record> &recs, const WideTree &wide, bool wide_in_use, const int wmin[3],
+                const int wmax[3], const int p[3], int max_depth, PatchSite &site) {
+    if (recs.empty()) return false;
+    for (int k = 0; k < 3; ++k)
+        if (p[k] < wmin[k] || p[k] >= wmax[k]) return false;
+    Box box;
+    for (int k = 0; k < 3; ++k) { box.mn[k] = wmin[k]; box.mx[k] = wmax[k]; }
+    uint32_t rec = 0;
+    int depth = 0;
+    long wnode = -1;        // wide node whose octree node is being descended (two octree levels per wide node)
+    int wshift = 0, level = 0, root_index = -1;
+    uint32_t hi = 0, parent_node = 0, parent_cell = 0;
+    bool found = false;
+    uint8_t path[16] = {};
+    for (;;) {
+        if (wide_in_use && wnode < 0)
+            for (size_t i = 0; i < wide.roots.size(); ++i)
+                if (wide.roots[i].record == rec) {
+                    wnode = (long)wide.roots[i].node;
+                    wshift = wide.roots[i].shift;
+                    level = 0;
+                    root_index = (int)i;
+                }
+        if (depth >= 1 && depth <= max_depth && depth <= 15) {
+            const bool at_wide_node = wnode >= 0 && level == 0;
+            if (!wide_in_use || at_wide_node) {
+                found = true;
+                site.depth = depth;
+                std::memcpy(site.path, path, sizeof path);
+                site.record = rec;
+                site.shift = at_wide_node ? wshift : -1;
+                site.root_index = at_wide_node ? root_index : -1;
+                site.parent_node = parent_node;
+                site.parent_cell = parent_cell;
+            }
+        }
+        if (depth >= 15 || depth >= max_depth) break;
+        uint32_t ci = 0;
+        for (int k = 0; k < 3; ++k) {
+            const int mid = box.mn[k] + ((box.mx[k] - box.mn[k]) >> 1);
+            if (p[k] >= mid) ci |= 1u << (2 - k);
+        }
+        uint32_t idx = 0;
+        if (child_of(recs, rec, ci, idx) != kInternal) break;
+        if (wnode >= 0) {
+            if (level == 0) {
+                hi = ci;
+                level = 1;
+            } else {
+                const uint32_t cx = (((hi >> 2) & 1u) << 1) | ((ci >> 2) & 1u), cy = (((hi >> 1) & 1u) << 1) | ((ci >> 1) & 1u),
+                               cz = ((hi & 1u) << 1) | (ci & 1u);
+                const uint32_t cell = (cx << 4) | (cy << 2) | cz;
+                const WideCell c = wide.cells[(size_t)wnode * 64 + cell];
+                if (c.w1 != kWideInternal) break;  // layouts out of step: leave the deeper levels alone
+                parent_node = (uint32_t)wnode;
+                parent_cell = cell;
+                root_index = -1;
+                wnode = (long)c.w0;
+                wshift -= 2;
+                level = 0;
+            }
+        }
+        path[depth] = (uint8_t)ci;
+        rec = idx;
+        box = child_box(box, ci);
+        ++depth;
+    }
+    return found;
+}
+
+bool apply_patch(std::vector<Record> &recs, WideTree &wide, bool wide_in_use, const PatchSite &site, const Record *sub,
+                 size_t n_sub, PatchRanges &out, std::string &why) {
+    out = PatchRanges();
+    out.records_appended_from = recs.size();
+    out.cells_appended_from = wide.cells.size();
+    if (!sub || n_sub < 1 || n_sub > (1u << 30)) { why = "empty sub-tree"; return false; }
+    if (site.record >= recs.size()) { why = "patch site out of range"; return false; }
+    // structural check (as vrt_upload_records): every child block lies after its parent and inside the sub-tree
+    std::vector<uint8_t> kind(n_sub, 0);  // 1 internal, 2 leaf
+    kind[0] = 1;
+    for (size_t i = 0; i < n_sub; ++i) {
+        if (kind[i] != 1) continue;
+        const uint32_t mask = sub[i].w0 & 0xffu, leaf_mask = (sub[i].w0 >> 8) & 0xffu, base = sub[i].w1;
+        const uint32_t n_child = (uint32_t)__builtin_popcount(mask);
+        if (n_child == 0) continue;
+        if (base <= i || (size_t)base + n_child > n_sub) { why = "sub-tree child index out of order or range"; return false; }
+        uint32_t rank = 0;
+        for (uint32_t ci = 0; ci < 8; ++ci) {
+            if (!((mask >> ci) & 1u)) continue;
+            const size_t idx = (size_t)base + rank++;
+            if (kind[idx] != 0) { why = "a sub-tree record has two parents"; return false; }
+            kind[idx] = ((leaf_mask >> ci) & 1u) ? 2 : 1;
+        }
+    }
+    // old record standing where each new record stands (same position under A, same kind), if any
+    constexpr uint32_t kNone = 0xffffffffu;
+    std::vector<uint32_t> old_of(n_sub, kNone);
+    old_of[0] = site.record;
+    for (size_t j = 0; j < n_sub; ++j) {
+        if (kind[j] != 1 || old_of[j] == kNone) continue;
+        const uint32_t mask = sub[j].w0 & 0xffu, leaf_mask = (sub[j].w0 >> 8) & 0xffu;
+        uint32_t rank = 0;
+        for (uint32_t ci = 0; ci < 8; ++ci) {
+            if (!((mask >> ci) & 1u)) continue;
+            const size_t sj = (size_t)sub[j].w1 + rank++;
+            uint32_t oi = 0;
+            const int ok = child_of(recs, old_of[j], ci, oi);
+            if (ok == (((leaf_mask >> ci) & 1u) ? kLeaf : kInternal)) old_of[sj] = oi;
+        }
+    }
+    // same[j]: the new sub-tree under j equals the old one under old_of[j] (bottom-up: children have larger indices)
+    std::vector<uint8_t> same(n_sub, 0);
+    for (size_t j = n_sub; j-- > 0;) {
+        if (old_of[j] == kNone) continue;
+        const Record &o = recs[old_of[j]];
+        if (kind[j] == 2) { same[j] = (o.w0 == sub[j].w0 && o.w1 == sub[j].w1); continue; }
+        if (o.w0 != sub[j].w0) continue;
+        bool all = true;
+        const uint32_t n_child = (uint32_t)__builtin_popcount(sub[j].w0 & 0xffu);
+        for (uint32_t r = 0; r < n_child && all; ++r) all = same[(size_t)sub[j].w1 + r] != 0;
+        same[j] = all;
+    }
+    // emit top-down: a changed internal node gets a new child block; unchanged children keep their old records'
+    // contents (and with them their old sub-trees), changed internal children are filled in when their turn comes
+    std::vector<size_t> where(n_sub, 0);  // global index of the record of sub[j]
+    where[0] = site.record;
+    for (size_t j = 0; j < n_sub; ++j) {
+        if (kind[j] != 1 || same[j] || (j != 0 && where[j] == 0)) continue;
+        const uint32_t n_child = (uint32_t)__builtin_popcount(sub[j].w0 & 0xffu);
+        const size_t block = recs.size();
+        for (uint32_t r = 0; r < n_child; ++r) {
+            const size_t sj = (size_t)sub[j].w1 + r;
+            if (kind[sj] == 2) recs.push_back(sub[sj]);
+            else if (same[sj]) { const Record keep = recs[old_of[sj]]; recs.push_back(keep); }
+            else { recs.push_back(Record{sub[sj].w0, 0u}); where[sj] = block + r; }
+        }
+        recs[where[j]].w0 = sub[j].w0;
+        recs[where[j]].w1 = n_child ? (uint32_t)block : 0u;
+    }
+    if (!wide_in_use) return true;
+    if (site.shift < 2) { out.wide_invalid = true; return true; }
+    if (same[0]) return true;  // nothing changed below A
+    uint32_t node = 0;
+    std::string wide_why;
+    const long old_node = site.root_index >= 0 ? (long)wide.roots[(size_t)site.root_index].node
+                                               : (long)wide.cells[(size_t)site.parent_node * 64 + site.parent_cell].w0;
+    if (!build_wide_node(recs, site.record, site.shift, wide, node, wide_why, old_node, out.records_appended_from, site.record)) {
+        out.wide_invalid = true;  // e.g. an internal node of unit size appeared: let the dispatcher re-derive everything
+        return true;
+    }
+    if (site.root_index >= 0) {
+        wide.roots[(size_t)site.root_index].node = node;
+    } else {
+        WideCell &c = wide.cells[(size_t)site.parent_node * 64 + site.parent_cell];
+        c.w0 = node;
+        c.w1 = kWideInternal;
+        out.cell_repointed = true;
+    }
+    return true;
 }
 
 }  // namespace vrt

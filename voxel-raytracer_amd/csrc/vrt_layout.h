@@ -66,6 +66,7 @@ struct WideRoot { uint32_t record; uint32_t node; int shift; };
 struct WideTree {
     std::vector<WideCell> cells;   // 64 per wide node
     std::vector<WideRoot> roots;
+    std::vector<uint32_t> node_record;  // per wide node: the record of its octree node (patches reuse unchanged nodes)
     uint32_t n_nodes = 0;
 };
 constexpr uint32_t kWideInternal = 0x80000000u;
@@ -79,5 +80,48 @@ bool build_wide(const std::vector<Record> &records, const int wmin[3], const int
 // Returns 1 and the leaf words for a leaf, 0 for empty space; mn/mx receive the node AABB.
 int wide_find_host(const std::vector<Record> &records, const WideTree &wt, const int wmin[3], const int wmax[3],
                    const int p[3], uint32_t &w0, uint32_t &w1, int mn[3], int mx[3]);
+
+// ---------------------------------------------------------------------------------------------
+// Edits without a rebuild. A voxel edit changes the octree below some ancestor A of the voxel and
+// nothing else. When A is an INTERNAL node before and after the edit, the device structures can be
+// patched: the caller re-emits A's sub-tree as records (level order, A = record 0, child indices local
+// to the sub-tree); the new sub-tree is compared with the old one and only the child blocks that differ --
+// normally the ones along the path to the edited voxel -- are APPENDED to the array (children still come
+// after their parents; unchanged sub-trees keep their records and are shared), A's own record is rewritten in
+// place, and -- when A is the octree node of a wide node -- the wide nodes along the same path are rebuilt
+// at the end of the cell array (wide nodes over unchanged records are reused) and the one cell (or root
+// table entry) that referred to A's old wide node is repointed. Replaced blocks and wide nodes stay behind as
+// unreferenced garbage until the next full upload.
+struct PatchSite {
+    int depth = 0;                 // of A below the root (>= 1)
+    uint8_t path[16] = {};         // child index taken at each level, root first
+    uint32_t record = 0;           // A's record
+    int shift = -1;                // log2 side of A when A is the octree node of a wide node, else -1
+    int root_index = -1;           // A is wide root `root_index`, or
+    uint32_t parent_node = 0;      //   cell `parent_cell` of wide node `parent_node` points at A's wide node
+    uint32_t parent_cell = 0;
+};
+
+// The deepest ancestor of voxel p, at depth 1..max_depth, that is an internal node and (when the wide layout is in
+// use) the octree node of a wide node. False when there is none: the edit needs a full upload.
+bool plan_patch(const std::vector<Record> &records, const WideTree &wide, bool wide_in_use, const int wmin[3],
+                const int wmax[3], const int p[3], int max_depth, PatchSite &site);
+
+struct PatchRanges {               // what changed, for the device copies
+    size_t records_appended_from = 0;   // records [from, size) are new
+    size_t cells_appended_from = 0;     // cells [from, size) are new
+    bool cell_repointed = false;        // cells[parent_node * 64 + parent_cell] changed
+    bool wide_invalid = false;          // the wide layout could not be patched: rebuild it from the records
+};
+
+// Texels the sub-tree under internal record `top` occupies in the reference's stream (one header per internal node,
+// one pointer per present child, two texels per leaf): u_texDim, which the shader folds into
+// the voxel ids it writes, is ceil(cbrt()) of the stream's total, so a patch has to keep that total current.
+size_t stream_texels(const Record *records, size_t n_records, uint32_t top);
+
+// sub: A's new sub-tree, n_sub records, sub[0] = A as an internal record (its child mask may be empty). False (nothing
+// modified) when sub is malformed.
+bool apply_patch(std::vector<Record> &records, WideTree &wide, bool wide_in_use, const PatchSite &site, const Record *sub,
+                 size_t n_sub, PatchRanges &out, std::string &why);
 
 }  // namespace vrt
