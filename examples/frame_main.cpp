@@ -10,6 +10,7 @@
 #include <octree.hpp>
 #include <voxReader.hpp>
 #include <vrt.h>
+#include <vrt_host.h>
 
 #include <cmath>
 #include <cstdio>
@@ -43,6 +44,29 @@ static void updateGPUTexture(Octree *tree) {
     free(texture_data);
 }
 
+// after the host octree was edited at voxel v: replace the smallest enclosing sub-tree on the device instead of
+// re-flattening and re-uploading everything; falls back to the reference's full upload
+static void patchGPUVoxel(Octree *tree, IVector3 v) {
+    vrt_patch plan;
+    for (int max_depth = 15; max_depth >= 1; max_depth = plan.depth - 1) {
+        if (vrt_patch_plan(g_vrt, v.x, v.y, v.z, max_depth, &plan) != VRT_OK) break;
+        if (vrth_octree_node_state(tree, plan.path, plan.depth) != 2) continue;
+        uint32_t *recs = nullptr;
+        size_t n = 0;
+        if (vrth_octree_subtree_records(tree, plan.path, plan.depth, &recs, &n) != 0) break;
+        const int rc = vrt_patch_apply(g_vrt, &plan, recs, n);
+        vrth_free(recs);
+        if (rc == VRT_OK) {
+            vrt_scene_info info;
+            vrt_get_scene_info(g_vrt, &info);
+            tex_dim = info.tex_dim;
+            return;
+        }
+        break;
+    }
+    updateGPUTexture(tree);
+}
+
 int main(int argc, char **argv) {
     const char *map = argc > 1 ? argv[1] : "tests/golden/maps/dragon.vox";
     const int screenWidth = argc > 2 ? atoi(argv[2]) : 320, screenHeight = argc > 3 ? atoi(argv[3]) : 180;
@@ -74,11 +98,13 @@ int main(int argc, char **argv) {
             prm.highlighted[0] = prm.highlighted[1] = prm.highlighted[2] = -1;
         }
         if (frame == 1 && hitNode && hitNode->has_voxel) {
-            // a "destroy" click followed by a "build" click (src/main.cpp:843-914): edit, then full re-upload
-            octree_remove(chunk0, hitNode->voxel.coord);
+            // a "destroy" click followed by a "build" click (src/main.cpp:843-914), each patched in place on the device
+            const IVector3 gone = hitNode->voxel.coord;
+            octree_remove(chunk0, gone);
+            patchGPUVoxel(chunk0, gone);
             Voxel light = {3.0f, 1.0f, 0.0f};
             octree_insert(chunk0, VoxelObjCreate(light, make_color_rgba(255, 210, 210, 255), {60, 70, 40}));
-            updateGPUTexture(chunk0);
+            patchGPUVoxel(chunk0, {60, 70, 40});
         }
         float invProj[16], invView[16], camPos[4];
         camera.FillDispatchBlock(screenWidth, screenHeight, invProj, invView, camPos);
