@@ -328,3 +328,50 @@ def test_records_from_tree_equal_records_from_texel_stream(V, product_scenes):
     pts = np.array([(x, y, z) for x in range(4) for y in range(4) for z in range(4)], np.int32)
     s.insert_many(pts, np.full(len(pts), 0x102030ff, np.uint32))
     assert s.records() is None
+
+
+@pytest.mark.parametrize("bounds", [((-1023, -1023, -1023), (1024, 1024, 1024)), ((0, 0, 0), (256, 256, 256)),
+                                    ((-7, -3, -5), (123, 70, 99))])
+def test_edit_patches_answer_like_rebuilt_layouts(V, bounds):
+    """vrt_patch_plan / vrt_patch_apply on the host structures (no device): after every insert / remove, the layouts
+    patched in place answer point lookups -- leaf words and node box, through the wide cells and through the records
+    alone -- exactly like layouts rebuilt from the edited tree's stream, and track its texel count."""
+    rng = np.random.default_rng(abs(sum(bounds[0])) + 99)
+    lo, hi = np.array(bounds[0]), np.array(bounds[1])
+    w = V.World(bounds[0], bounds[1])
+    span = np.minimum(hi - lo, 120)
+    base = np.maximum(lo, 0)
+    for _ in range(6):
+        c = base + rng.integers(0, span, size=3)
+        xyz = np.clip(c + rng.integers(-4, 5, size=(40, 3)), lo, hi - 1).astype(np.int32)
+        w.insert_many(xyz, np.full(len(xyz), 0xa0a0a0ff, np.uint32))
+    placed = []
+    patched = appended = 0
+    before, _ = w.flatten()
+    for step in range(120):
+        kind = step % 4
+        if kind == 3 and placed:
+            v = placed.pop(int(rng.integers(0, len(placed))))
+            w.remove(*v)
+        else:
+            if kind == 0:      # near the geometry
+                v = tuple(int(t) for t in np.clip(base + rng.integers(0, span, size=3), lo, hi - 1))
+            elif kind == 1:    # anywhere in the world
+                v = tuple(int(t) for t in rng.integers(lo, hi, size=3))
+            else:              # next to something placed earlier
+                q = placed[int(rng.integers(0, len(placed)))] if placed else tuple(int(t) for t in base)
+                v = tuple(int(t) for t in np.clip(np.array(q) + rng.integers(-1, 2, size=3), lo, hi - 1))
+            w.insert(v[0], v[1], v[2], int(rng.choice([0x50b43cff, 0xc8dcff50, 0x11223300])), float(rng.choice([3.0, 1.5])), 0.0, 0.0)
+            placed.append(v)
+        after, _ = w.flatten()
+        near = np.clip(np.array(v) + rng.integers(-9, 10, size=(150, 3)), lo, hi - 1)
+        far = rng.integers(lo, hi, size=(150, 3))
+        bad, depth, n_rec, n_cells, texels_ok = V.patch_check(before, after, v, np.concatenate([near, far, [v]]), bounds[0], bounds[1])
+        assert bad == 0, (step, v, depth)
+        if depth:
+            patched += 1
+            appended += n_rec
+            assert texels_ok, (step, v, depth)
+        before = after
+    assert patched >= 60, patched
+    assert appended / patched < 200, appended / patched          # only the blocks along the path are appended

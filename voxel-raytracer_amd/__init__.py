@@ -300,6 +300,26 @@ def build_layout(texels):
     return rec, info
 
 
+def patch_check(texels_before, texels_after, voxel, points, world_min=(-1023, -1023, -1023), world_max=(1024, 1024, 1024)):
+    """Host-only (vrt_debug_patch_check): patch the layouts of the tree before an edit of `voxel` with the sub-tree of
+    the tree after it and compare point lookups with freshly built layouts.
+    -> (mismatching points, depth of the node replaced or 0, records appended, wide cells appended, texel count ok)"""
+    L = hip_lib()
+    L.vrt_debug_patch_check.restype = C.c_long
+    L.vrt_debug_patch_check.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                        C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    tb = np.ascontiguousarray(texels_before, np.uint8)
+    ta = np.ascontiguousarray(texels_after, np.uint8)
+    pts = np.ascontiguousarray(points, np.int32).reshape(-1, 3)
+    info = np.zeros(4, np.uint32)
+    r = L.vrt_debug_patch_check(tb.ctypes.data if tb.size else None, tb.size, ta.ctypes.data if ta.size else None, ta.size,
+                                (C.c_int32 * 3)(*world_min), (C.c_int32 * 3)(*world_max), int(voxel[0]), int(voxel[1]),
+                                int(voxel[2]), pts.ctypes.data, pts.shape[0], info.ctypes.data)
+    if r < 0:
+        raise VrtError(f"vrt_debug_patch_check failed ({r})")
+    return int(r), int(info[0]), int(info[1]), int(info[2]), bool(info[3])
+
+
 def wide_find(texels, points, world_min=(-1023, -1023, -1023), world_max=(1024, 1024, 1024)):
     """Host-only: point queries through the wide (64-cell) layout the default kernels read.
     -> (uint32[n,8] = w0, w1, mn[3], mx[3], (wide nodes, roots)), or None when the scene has no wide form."""

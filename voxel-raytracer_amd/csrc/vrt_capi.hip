@@ -870,6 +870,63 @@ int vrt_debug_wide_find(const uint8_t *texels, size_t used_bytes, const int32_t 
     return VRT_OK;
 }
 
+// Host-only check of the edit patch (no device): lays out the tree before and after an edit of voxel (x, y, z) from
+// their texel streams, patches the "before" structures with the sub-tree taken from the "after" ones, and counts the
+// query points whose lookup (leaf words + node box), through the wide layout and through the records alone, differs
+// between the patched and the freshly built structures. info: [0] depth of the node replaced (0: no patchable
+// ancestor, nothing compared), [1] records appended, [2] wide cells appended, [3] 1 when the stream's texel count
+// tracked by the patch equals the "after" stream's. Returns the number of differing points or a negative code.
+long vrt_debug_patch_check(const uint8_t *before, size_t before_bytes, const uint8_t *after, size_t after_bytes,
+                           const int32_t wmin[3], const int32_t wmax[3], int x, int y, int z, const int32_t *points, size_t n,
+                           uint32_t *info) {
+    vrt::Layout lb, la;
+    std::string err;
+    if (!vrt::build_layout(before, before_bytes, lb, err) || !vrt::build_layout(after, after_bytes, la, err)) return VRT_E_MALFORMED;
+    vrt::WideTree wb, wa;
+    const bool wide_b = !vrt::has_unit_internal_node(lb.records, wmin, wmax) && vrt::build_wide(lb.records, wmin, wmax, wb, err);
+    const bool wide_a = !vrt::has_unit_internal_node(la.records, wmin, wmax) && vrt::build_wide(la.records, wmin, wmax, wa, err);
+    if (info) info[0] = info[1] = info[2] = info[3] = 0;
+    const int p[3] = {x, y, z};
+    vrt::PatchSite site;
+    std::vector<vrt::Record> sub;
+    int max_depth = 15;
+    bool have = false;
+    while (max_depth >= 1 && vrt::plan_patch(lb.records, wb, wide_b, wmin, wmax, p, max_depth, site)) {
+        if (vrt::extract_subtree(la.records, site.path, site.depth, sub)) { have = true; break; }
+        max_depth = site.depth - 1;
+    }
+    if (!have) return 0;
+    const size_t t_before = vrt::stream_texels(lb.records.data(), lb.records.size(), site.record);
+    const size_t t_after = vrt::stream_texels(sub.data(), sub.size(), 0);
+    const size_t n_rec = lb.records.size(), n_cells = wb.cells.size();
+    vrt::PatchRanges rg;
+    if (!vrt::apply_patch(lb.records, wb, wide_b, site, sub.data(), sub.size(), rg, err)) return VRT_E_MALFORMED;
+    bool wide_p = wide_b;
+    if (wide_b && rg.wide_invalid) wide_p = !vrt::has_unit_internal_node(lb.records, wmin, wmax) && vrt::build_wide(lb.records, wmin, wmax, wb, err);
+    if (info) {
+        info[0] = (uint32_t)site.depth;
+        info[1] = (uint32_t)(lb.records.size() - n_rec);
+        info[2] = (uint32_t)(wb.cells.size() > n_cells ? wb.cells.size() - n_cells : 0);
+        info[3] = (before_bytes / 4 - t_before + t_after == after_bytes / 4) ? 1u : 0u;
+    }
+    if (wide_p != wide_a) return VRT_E_STATE;
+    const vrt::WideTree none;
+    long bad = 0;
+    for (size_t i = 0; i < n; ++i) {
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 0 && !wide_p) continue;
+            uint32_t a0, a1, b0, b1;
+            int amn[3], amx[3], bmn[3], bmx[3];
+            const int ka = vrt::wide_find_host(lb.records, pass == 0 ? wb : none, wmin, wmax, points + 3 * i, a0, a1, amn, amx);
+            const int kb = vrt::wide_find_host(la.records, pass == 0 ? wa : none, wmin, wmax, points + 3 * i, b0, b1, bmn, bmx);
+            bool same = ka == kb && a0 == b0 && a1 == b1;
+            for (int k = 0; k < 3; ++k) same = same && amn[k] == bmn[k] && amx[k] == bmx[k];
+            if (!same) { ++bad; break; }
+        }
+    }
+    return bad;
+}
+
 // Host-only view of the device layout for tests that run without a GPU:
 // writes up to cap records (8 bytes each) and returns the record count, or <0.
 long vrt_debug_build_layout(const uint8_t *texels, size_t used_bytes, uint32_t *records_out, size_t cap_records,

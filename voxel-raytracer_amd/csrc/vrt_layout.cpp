@@ -309,9 +309,42 @@ size_t stream_texels(const Record *recs, size_t n, uint32_t top) {
     return total;
 }
 
-bool plan_patch(const std::vector<Record> &recs, const WideTree &wide, bool wide_in_use, const int wmin[3],
-                const int wmax[3], const int p[3], int max_depth, PatchSite &site) {
+bool extract_subtree(const std::vector<Record> &recs, const uint8_t *path, int depth, std::vector<Record> &sub) {
+    sub.clear();
     if (recs.empty()) return false;
+    uint32_t rec = 0;
+    for (int d = 0; d < depth; ++d) {
+        uint32_t idx = 0;
+        if (path[d] > 7 || child_of(recs, rec, path[d], idx) != kInternal) return false;
+        rec = idx;
+    }
+    std::vector<uint32_t> src(1, rec);  // source record of each emitted internal record, in emission order
+    sub.push_back(recs[rec]);
+    std::vector<size_t> internal_at(1, 0);
+    for (size_t head = 0; head < src.size(); ++head) {
+        const Record r = recs[src[head]];
+        const uint32_t mask = r.w0 & 0xffu, leaf_mask = (r.w0 >> 8) & 0xffu;
+        const size_t at = internal_at[head];
+        sub[at].w1 = (uint32_t)sub.size();
+        uint32_t rank = 0;
+        for (uint32_t ci = 0; ci < 8; ++ci) {
+            if (!((mask >> ci) & 1u)) continue;
+            const size_t idx = (size_t)r.w1 + rank++;
+            if (idx >= recs.size()) return false;
+            if (!((leaf_mask >> ci) & 1u)) {
+                src.push_back((uint32_t)idx);
+                internal_at.push_back(sub.size());
+            }
+            sub.push_back(recs[idx]);
+        }
+    }
+    return true;
+}
+
+bool plan_patch(const std::vector<Record> &recs, const WideTree &wide, bool wide_in_use, const int wmin[3],
+                const int wmax[3], const int p[3], int max_depth, PatchSite &site) {  // wide_in_use: by value, adjusted below
+    if (recs.empty()) return false;
+    if (wide.roots.empty()) wide_in_use = false;  // nothing aligned in this world: the kernels walk the records alone
     for (int k = 0; k < 3; ++k)
         if (p[k] < wmin[k] || p[k] >= wmax[k]) return false;
     Box box;
@@ -448,7 +481,7 @@ bool apply_patch(std::vector<Record> &recs, WideTree &wide, bool wide_in_use, co
         recs[where[j]].w0 = sub[j].w0;
         recs[where[j]].w1 = n_child ? (uint32_t)block : 0u;
     }
-    if (!wide_in_use) return true;
+    if (!wide_in_use || wide.roots.empty()) return true;
     if (site.shift < 2) { out.wide_invalid = true; return true; }
     if (same[0]) return true;  // nothing changed below A
     uint32_t node = 0;

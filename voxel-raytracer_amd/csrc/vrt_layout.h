@@ -119,6 +119,10 @@ struct PatchRanges {               // what changed, for the device copies
 // the voxel ids it writes, is ceil(cbrt()) of the stream's total, so a patch has to keep that total current.
 size_t stream_texels(const Record *records, size_t n_records, uint32_t top);
 
+// The sub-tree under the node reached from the root by `depth` child indices, re-indexed from 0 (what the host
+// library emits from the pointer octree). False when the path leaves the tree or does not end at an internal node.
+bool extract_subtree(const std::vector<Record> &records, const uint8_t *path, int depth, std::vector<Record> &sub);
+
 // sub: A's new sub-tree, n_sub records, sub[0] = A as an internal record (its child mask may be empty). False (nothing
 // modified) when sub is malformed.
 bool apply_patch(std::vector<Record> &records, WideTree &wide, bool wide_in_use, const PatchSite &site, const Record *sub,
