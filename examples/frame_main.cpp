@@ -53,7 +53,7 @@ static void patchGPUVoxel(Octree *tree, IVector3 v) {
         if (vrth_octree_node_state(tree, plan.path, plan.depth) != 2) continue;
         uint32_t *recs = nullptr;
         size_t n = 0;
-        if (vrth_octree_subtree_records(tree, plan.path, plan.depth, &recs, &n) != 0) break;
+        if (vrth_octree_path_records(tree, plan.path, plan.depth, v.x, v.y, v.z, &recs, &n) != 0) break;
         const int rc = vrt_patch_apply(g_vrt, &plan, recs, n);
         vrth_free(recs);
         if (rc == VRT_OK) {

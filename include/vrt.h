@@ -85,7 +85,8 @@ int vrt_get_scene_info(const vrt_ctx *ctx, vrt_scene_info *info);
  *   1. vrt_patch_plan() names the deepest ancestor A of the voxel (depth <= max_depth) whose sub-tree can be replaced
  *      on the device: depth below the root and the child index taken at each level;
  *   2. the host library says whether A is still an internal node (vrth_octree_node_state) -- if not, plan again with
- *      max_depth = depth - 1 -- and emits A's new sub-tree (vrth_octree_subtree_records);
+ *      max_depth = depth - 1 -- and emits A's new sub-tree (vrth_octree_path_records: just the nodes that contain the
+ *      voxel, or vrth_octree_subtree_records: all of it);
  *   3. vrt_patch_apply() appends those records, rewrites A's record, rebuilds A's part of the wide layout and copies
  *      only what changed to the device (after waiting for dispatches in flight).
  * vrt_patch_plan returns VRT_E_STATE when no ancestor qualifies (use vrt_upload_octree / vrt_upload_records).

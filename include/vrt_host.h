@@ -57,6 +57,12 @@ int vrth_octree_records(void *octree_root, uint32_t **records, size_t *n_records
  * child indices local to the sub-tree; vrth_free). */
 int vrth_octree_node_state(void *octree_root, const uint8_t *path, int depth);
 int vrth_octree_subtree_records(void *octree_root, const uint8_t *path, int depth, uint32_t **records, size_t *n_records);
+/* the sub-tree for an edit of voxel (x, y, z): only the nodes that contain the voxel are walked and emitted, every
+ * other internal child is a "keep" record {0xffffffff, 0xffffffff} that vrt_patch_apply resolves to what is there */
+int vrth_octree_path_records(void *octree_root, const uint8_t *path, int depth, int x, int y, int z, uint32_t **records,
+                             size_t *n_records);
+int vrth_world_path_records(vrth_world *w, const uint8_t *path, int depth, int x, int y, int z, uint32_t **records,
+                            size_t *n_records);
 int vrth_world_node_state(vrth_world *w, const uint8_t *path, int depth);
 int vrth_world_subtree_records(vrth_world *w, const uint8_t *path, int depth, uint32_t **records, size_t *n_records);
 void vrth_free(void *p);

@@ -366,8 +366,11 @@ def test_edit_patches_answer_like_rebuilt_layouts(V, bounds):
         after, _ = w.flatten()
         near = np.clip(np.array(v) + rng.integers(-9, 10, size=(150, 3)), lo, hi - 1)
         far = rng.integers(lo, hi, size=(150, 3))
-        bad, depth, n_rec, n_cells, texels_ok = V.patch_check(before, after, v, np.concatenate([near, far, [v]]), bounds[0], bounds[1])
+        pts = np.concatenate([near, far, [v]])
+        bad, depth, n_rec, n_cells, texels_ok = V.patch_check(before, after, v, pts, bounds[0], bounds[1])
         assert bad == 0, (step, v, depth)
+        # the same with a sub-tree that carries only the path to the voxel (every other internal child: "keep")
+        assert V.patch_check(before, after, v, pts, bounds[0], bounds[1], sparse=True) == (0, depth, n_rec, n_cells, texels_ok), (step, v)
         if depth:
             patched += 1
             appended += n_rec

@@ -300,21 +300,22 @@ def build_layout(texels):
     return rec, info
 
 
-def patch_check(texels_before, texels_after, voxel, points, world_min=(-1023, -1023, -1023), world_max=(1024, 1024, 1024)):
+def patch_check(texels_before, texels_after, voxel, points, world_min=(-1023, -1023, -1023), world_max=(1024, 1024, 1024),
+                sparse=False):
     """Host-only (vrt_debug_patch_check): patch the layouts of the tree before an edit of `voxel` with the sub-tree of
     the tree after it and compare point lookups with freshly built layouts.
     -> (mismatching points, depth of the node replaced or 0, records appended, wide cells appended, texel count ok)"""
     L = hip_lib()
     L.vrt_debug_patch_check.restype = C.c_long
     L.vrt_debug_patch_check.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
-                                        C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+                                        C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
     tb = np.ascontiguousarray(texels_before, np.uint8)
     ta = np.ascontiguousarray(texels_after, np.uint8)
     pts = np.ascontiguousarray(points, np.int32).reshape(-1, 3)
     info = np.zeros(4, np.uint32)
     r = L.vrt_debug_patch_check(tb.ctypes.data if tb.size else None, tb.size, ta.ctypes.data if ta.size else None, ta.size,
                                 (C.c_int32 * 3)(*world_min), (C.c_int32 * 3)(*world_max), int(voxel[0]), int(voxel[1]),
-                                int(voxel[2]), pts.ctypes.data, pts.shape[0], info.ctypes.data)
+                                int(voxel[2]), pts.ctypes.data, pts.shape[0], info.ctypes.data, 1 if sparse else 0)
     if r < 0:
         raise VrtError(f"vrt_debug_patch_check failed ({r})")
     return int(r), int(info[0]), int(info[1]), int(info[2]), bool(info[3])
@@ -438,19 +439,19 @@ class Context:
 
     def patch_voxel(self, world, x, y, z, max_depth=15):
         """After `world` has been edited at voxel (x, y, z): replaces the smallest enclosing sub-tree on the device
-        (vrt_patch_plan / vrth_world_subtree_records / vrt_patch_apply). Returns the depth of the node replaced, or None
+        (vrt_patch_plan / vrth_world_path_records / vrt_patch_apply). Returns the depth of the node replaced, or None
         when the edit needs a full upload (nothing was changed on the device then)."""
         H = host_lib()
         H.vrth_world_node_state.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int]
-        H.vrth_world_subtree_records.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_void_p),
-                                                 C.POINTER(C.c_size_t)]
+        H.vrth_world_path_records.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         plan = Patch()
         while max_depth >= 1:
             if self._L.vrt_patch_plan(self._h, x, y, z, max_depth, C.byref(plan)) != 0:
                 return None
             if H.vrth_world_node_state(world._h, plan.path, plan.depth) == 2:
                 p, n = C.c_void_p(), C.c_size_t(0)
-                if H.vrth_world_subtree_records(world._h, plan.path, plan.depth, C.byref(p), C.byref(n)) != 0:
+                if H.vrth_world_path_records(world._h, plan.path, plan.depth, x, y, z, C.byref(p), C.byref(n)) != 0:
                     return None
                 try:
                     self._chk(self._L.vrt_patch_apply(self._h, C.byref(plan), p, n.value))

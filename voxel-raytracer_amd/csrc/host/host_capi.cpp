@@ -170,7 +170,9 @@ inline bool counted(const Octree *c) { return c && (c->has_voxel || c->children)
 
 // Records of the sub-tree under `top` in level order, top = record 0 (child indices local to the sub-tree);
 // `top_depth` = depth of `top` below the root, for the 16-iteration truncation of the shader's descent.
-void emit_records(const Octree *top, uint32_t top_depth, std::vector<uint32_t> &out) {
+// toward != NULL: only children whose box holds that voxel are expanded; every other internal child becomes a
+// "keep" record {0xffffffff, 0xffffffff} (the child and everything below it is as it was: vrt_patch_apply shares it).
+void emit_records(const Octree *top, uint32_t top_depth, std::vector<uint32_t> &out, const int *toward = nullptr) {
     struct Item { const Octree *n; uint32_t rec, depth; };
     out.assign(2, 0u);
     std::vector<Item> queue;
@@ -196,6 +198,11 @@ void emit_records(const Octree *top, uint32_t top_depth, std::vector<uint32_t> &
                 out.push_back(w0);
                 out.push_back(w1);
                 leaf_mask |= 1u << i;
+            } else if (toward && !(toward[0] >= c->left_bot_back.x && toward[0] < c->right_top_front.x &&
+                                   toward[1] >= c->left_bot_back.y && toward[1] < c->right_top_front.y &&
+                                   toward[2] >= c->left_bot_back.z && toward[2] < c->right_top_front.z)) {
+                out.push_back(0xffffffffu);
+                out.push_back(0xffffffffu);
             } else {
                 out.push_back(0u);
                 out.push_back(0u);
@@ -257,6 +264,23 @@ int vrth_octree_subtree_records(void *octree_root, const uint8_t *path, int dept
     std::vector<uint32_t> out;
     emit_records(n, (uint32_t)depth, out);
     return hand_over(out, records, n_records);
+}
+
+// the same sub-tree for an edit of voxel (x, y, z): only the nodes that contain the voxel are walked
+int vrth_octree_path_records(void *octree_root, const uint8_t *path, int depth, int x, int y, int z, uint32_t **records,
+                             size_t *n_records) {
+    if (!octree_root || (!path && depth > 0) || depth < 0 || depth > 15 || !records || !n_records) return -1;
+    const Octree *n = walk(static_cast<const Octree *>(octree_root), path, depth);
+    if (!n || !n->children) return -2;
+    const int toward[3] = {x, y, z};
+    std::vector<uint32_t> out;
+    emit_records(n, (uint32_t)depth, out, toward);
+    return hand_over(out, records, n_records);
+}
+
+int vrth_world_path_records(vrth_world *w, const uint8_t *path, int depth, int x, int y, int z, uint32_t **records,
+                            size_t *n_records) {
+    return w ? vrth_octree_path_records(w->root, path, depth, x, y, z, records, n_records) : -1;
 }
 
 int vrth_world_node_state(vrth_world *w, const uint8_t *path, int depth) {

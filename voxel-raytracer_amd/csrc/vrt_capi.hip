@@ -534,8 +534,6 @@ int vrt_patch_apply(vrt_ctx *c, const vrt_patch *patch, const uint32_t *subtree_
             site.depth != patch->depth || std::memcmp(site.path, patch->path, (size_t)patch->depth) != 0)
             return fail(c, VRT_E_STATE, "vrt_patch_apply: the path does not name a patchable node of the uploaded tree");
     }
-    const size_t texels_before = vrt::stream_texels(c->host_records.data(), c->host_records.size(), site.record);
-    const size_t texels_after = vrt::stream_texels(reinterpret_cast<const vrt::Record *>(subtree_records), n_records, 0);
     vrt::PatchRanges rg;
     std::string why;
     if (!vrt::apply_patch(c->host_records, c->wide, c->wide_ok, site, reinterpret_cast<const vrt::Record *>(subtree_records),
@@ -559,7 +557,7 @@ int vrt_patch_apply(vrt_ctx *c, const vrt_patch *patch, const uint32_t *subtree_
         VRT_HIP(c, hipMemcpy(c->d_nodes + site.record, c->host_records.data() + site.record, sizeof(vrt::Record), hipMemcpyHostToDevice));
     }
     c->info.n_records = (uint32_t)c->host_records.size();
-    c->stream_texels = c->stream_texels - texels_before + texels_after;
+    c->stream_texels = (size_t)((long)c->stream_texels + rg.texel_delta);
     c->info.n_texels = (uint32_t)c->stream_texels;
     if (c->dim_from_texels) c->info.tex_dim = dim_of_texels(c->stream_texels);  // what updateGPUTexture would pass now
     if (c->wide_ok) {
@@ -875,10 +873,11 @@ int vrt_debug_wide_find(const uint8_t *texels, size_t used_bytes, const int32_t 
 // query points whose lookup (leaf words + node box), through the wide layout and through the records alone, differs
 // between the patched and the freshly built structures. info: [0] depth of the node replaced (0: no patchable
 // ancestor, nothing compared), [1] records appended, [2] wide cells appended, [3] 1 when the stream's texel count
-// tracked by the patch equals the "after" stream's. Returns the number of differing points or a negative code.
+// tracked by the patch equals the "after" stream's. sparse: the sub-tree carries only the nodes that contain the
+// voxel, everything else as kKeep records. Returns the number of differing points or a negative code.
 long vrt_debug_patch_check(const uint8_t *before, size_t before_bytes, const uint8_t *after, size_t after_bytes,
                            const int32_t wmin[3], const int32_t wmax[3], int x, int y, int z, const int32_t *points, size_t n,
-                           uint32_t *info) {
+                           uint32_t *info, int sparse) {
     vrt::Layout lb, la;
     std::string err;
     if (!vrt::build_layout(before, before_bytes, lb, err) || !vrt::build_layout(after, after_bytes, la, err)) return VRT_E_MALFORMED;
@@ -892,12 +891,10 @@ long vrt_debug_patch_check(const uint8_t *before, size_t before_bytes, const uin
     int max_depth = 15;
     bool have = false;
     while (max_depth >= 1 && vrt::plan_patch(lb.records, wb, wide_b, wmin, wmax, p, max_depth, site)) {
-        if (vrt::extract_subtree(la.records, site.path, site.depth, sub)) { have = true; break; }
+        if (vrt::extract_subtree(la.records, site.path, site.depth, sub, sparse ? p : nullptr, wmin, wmax)) { have = true; break; }
         max_depth = site.depth - 1;
     }
     if (!have) return 0;
-    const size_t t_before = vrt::stream_texels(lb.records.data(), lb.records.size(), site.record);
-    const size_t t_after = vrt::stream_texels(sub.data(), sub.size(), 0);
     const size_t n_rec = lb.records.size(), n_cells = wb.cells.size();
     vrt::PatchRanges rg;
     if (!vrt::apply_patch(lb.records, wb, wide_b, site, sub.data(), sub.size(), rg, err)) return VRT_E_MALFORMED;
@@ -907,7 +904,7 @@ long vrt_debug_patch_check(const uint8_t *before, size_t before_bytes, const uin
         info[0] = (uint32_t)site.depth;
         info[1] = (uint32_t)(lb.records.size() - n_rec);
         info[2] = (uint32_t)(wb.cells.size() > n_cells ? wb.cells.size() - n_cells : 0);
-        info[3] = (before_bytes / 4 - t_before + t_after == after_bytes / 4) ? 1u : 0u;
+        info[3] = ((long)(before_bytes / 4) + rg.texel_delta == (long)(after_bytes / 4)) ? 1u : 0u;
     }
     if (wide_p != wide_a) return VRT_E_STATE;
     const vrt::WideTree none;

@@ -1,6 +1,7 @@
 // vrt_layout.cpp -- see vrt_layout.h
 #include "vrt_layout.h"
 
+#include <algorithm>
 #include <cstring>
 
 #include <deque>
@@ -309,33 +310,46 @@ size_t stream_texels(const Record *recs, size_t n, uint32_t top) {
     return total;
 }
 
-bool extract_subtree(const std::vector<Record> &recs, const uint8_t *path, int depth, std::vector<Record> &sub) {
+bool extract_subtree(const std::vector<Record> &recs, const uint8_t *path, int depth, std::vector<Record> &sub,
+                     const int *toward, const int *wmin, const int *wmax) {
     sub.clear();
     if (recs.empty()) return false;
+    Box box{{0, 0, 0}, {0, 0, 0}};
+    if (toward)
+        for (int k = 0; k < 3; ++k) { box.mn[k] = wmin[k]; box.mx[k] = wmax[k]; }
     uint32_t rec = 0;
     for (int d = 0; d < depth; ++d) {
         uint32_t idx = 0;
         if (path[d] > 7 || child_of(recs, rec, path[d], idx) != kInternal) return false;
         rec = idx;
+        if (toward) box = child_box(box, path[d]);
     }
-    std::vector<uint32_t> src(1, rec);  // source record of each emitted internal record, in emission order
+    struct Item { uint32_t src; size_t at; Box box; };
+    std::vector<Item> queue(1, Item{rec, 0, box});
     sub.push_back(recs[rec]);
-    std::vector<size_t> internal_at(1, 0);
-    for (size_t head = 0; head < src.size(); ++head) {
-        const Record r = recs[src[head]];
+    for (size_t head = 0; head < queue.size(); ++head) {
+        const Item it = queue[head];
+        const Record r = recs[it.src];
         const uint32_t mask = r.w0 & 0xffu, leaf_mask = (r.w0 >> 8) & 0xffu;
-        const size_t at = internal_at[head];
-        sub[at].w1 = (uint32_t)sub.size();
+        sub[it.at].w1 = (uint32_t)sub.size();
         uint32_t rank = 0;
         for (uint32_t ci = 0; ci < 8; ++ci) {
             if (!((mask >> ci) & 1u)) continue;
             const size_t idx = (size_t)r.w1 + rank++;
             if (idx >= recs.size()) return false;
-            if (!((leaf_mask >> ci) & 1u)) {
-                src.push_back((uint32_t)idx);
-                internal_at.push_back(sub.size());
+            if ((leaf_mask >> ci) & 1u) { sub.push_back(recs[idx]); continue; }
+            Box cb = it.box;
+            bool expand = true;
+            if (toward) {
+                cb = child_box(it.box, ci);
+                for (int k = 0; k < 3; ++k) expand = expand && toward[k] >= cb.mn[k] && toward[k] < cb.mx[k];
             }
-            sub.push_back(recs[idx]);
+            if (expand) {
+                queue.push_back(Item{(uint32_t)idx, sub.size(), cb});
+                sub.push_back(recs[idx]);
+            } else {
+                sub.push_back(Record{kKeep, kKeep});
+            }
         }
     }
     return true;
@@ -420,7 +434,7 @@ bool apply_patch(std::vector<Record> &recs, WideTree &wide, bool wide_in_use, co
     if (!sub || n_sub < 1 || n_sub > (1u << 30)) { why = "empty sub-tree"; return false; }
     if (site.record >= recs.size()) { why = "patch site out of range"; return false; }
     // structural check (as vrt_upload_records): every child block lies after its parent and inside the sub-tree
-    std::vector<uint8_t> kind(n_sub, 0);  // 1 internal, 2 leaf
+    std::vector<uint8_t> kind(n_sub, 0);  // 1 internal, 2 leaf, 3 internal and unchanged (kKeep)
     kind[0] = 1;
     for (size_t i = 0; i < n_sub; ++i) {
         if (kind[i] != 1) continue;
@@ -433,7 +447,7 @@ bool apply_patch(std::vector<Record> &recs, WideTree &wide, bool wide_in_use, co
             if (!((mask >> ci) & 1u)) continue;
             const size_t idx = (size_t)base + rank++;
             if (kind[idx] != 0) { why = "a sub-tree record has two parents"; return false; }
-            kind[idx] = ((leaf_mask >> ci) & 1u) ? 2 : 1;
+            kind[idx] = ((leaf_mask >> ci) & 1u) ? 2 : ((sub[idx].w0 == kKeep && sub[idx].w1 == kKeep) ? 3 : 1);  // 3: kept as it was
         }
     }
     // old record standing where each new record stands (same position under A, same kind), if any
@@ -450,13 +464,48 @@ bool apply_patch(std::vector<Record> &recs, WideTree &wide, bool wide_in_use, co
             uint32_t oi = 0;
             const int ok = child_of(recs, old_of[j], ci, oi);
             if (ok == (((leaf_mask >> ci) & 1u) ? kLeaf : kInternal)) old_of[sj] = oi;
+            else if (kind[sj] == 3) { why = "a kept child has no internal counterpart in the uploaded tree"; return false; }
         }
+    }
+    // the stream's texel count: what the expanded part of the new sub-tree takes minus what it replaces (kept
+    // sub-trees count on neither side; the pointer texel to one belongs to its parent)
+    {
+        std::vector<uint32_t> kept;
+        size_t t_new = 0;
+        for (size_t j = 0; j < n_sub; ++j) {
+            if (kind[j] == 3) {
+                if (old_of[j] == kNone) { why = "a kept child has no counterpart in the uploaded tree"; return false; }
+                kept.push_back(old_of[j]);
+            }
+            if (kind[j] != 1) continue;
+            const uint32_t mask = sub[j].w0 & 0xffu, leaf_mask = (sub[j].w0 >> 8) & mask;
+            t_new += 1 + (size_t)__builtin_popcount(mask) + 2 * (size_t)__builtin_popcount(leaf_mask);
+        }
+        std::sort(kept.begin(), kept.end());
+        size_t t_old = 0;
+        std::vector<uint32_t> todo(1, site.record);
+        while (!todo.empty()) {
+            const uint32_t r = todo.back();
+            todo.pop_back();
+            const uint32_t mask = recs[r].w0 & 0xffu, leaf_mask = (recs[r].w0 >> 8) & 0xffu;
+            t_old += 1 + (size_t)__builtin_popcount(mask);
+            uint32_t rank = 0;
+            for (uint32_t ci = 0; ci < 8; ++ci) {
+                if (!((mask >> ci) & 1u)) continue;
+                const size_t idx = (size_t)recs[r].w1 + rank++;
+                if (idx >= recs.size()) continue;
+                if ((leaf_mask >> ci) & 1u) t_old += 2;
+                else if (!std::binary_search(kept.begin(), kept.end(), (uint32_t)idx)) todo.push_back((uint32_t)idx);
+            }
+        }
+        out.texel_delta = (long)t_new - (long)t_old;
     }
     // same[j]: the new sub-tree under j equals the old one under old_of[j] (bottom-up: children have larger indices)
     std::vector<uint8_t> same(n_sub, 0);
     for (size_t j = n_sub; j-- > 0;) {
         if (old_of[j] == kNone) continue;
         const Record &o = recs[old_of[j]];
+        if (kind[j] == 3) { same[j] = 1; continue; }
         if (kind[j] == 2) { same[j] = (o.w0 == sub[j].w0 && o.w1 == sub[j].w1); continue; }
         if (o.w0 != sub[j].w0) continue;
         bool all = true;

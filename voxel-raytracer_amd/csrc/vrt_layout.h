@@ -107,11 +107,16 @@ struct PatchSite {
 bool plan_patch(const std::vector<Record> &records, const WideTree &wide, bool wide_in_use, const int wmin[3],
                 const int wmax[3], const int p[3], int max_depth, PatchSite &site);
 
+// A record {kKeep, kKeep} in an internal child's place of an emitted sub-tree means "this child and everything below
+// it is unchanged": the emitter then only has to walk the nodes that contain the edited voxel.
+constexpr uint32_t kKeep = 0xffffffffu;
+
 struct PatchRanges {               // what changed, for the device copies
     size_t records_appended_from = 0;   // records [from, size) are new
     size_t cells_appended_from = 0;     // cells [from, size) are new
     bool cell_repointed = false;        // cells[parent_node * 64 + parent_cell] changed
     bool wide_invalid = false;          // the wide layout could not be patched: rebuild it from the records
+    long texel_delta = 0;               // change of the reference stream's texel count (stream_texels) by this patch
 };
 
 // Texels the sub-tree under internal record `top` occupies in the reference's stream (one header per internal node,
@@ -121,7 +126,10 @@ size_t stream_texels(const Record *records, size_t n_records, uint32_t top);
 
 // The sub-tree under the node reached from the root by `depth` child indices, re-indexed from 0 (what the host
 // library emits from the pointer octree). False when the path leaves the tree or does not end at an internal node.
-bool extract_subtree(const std::vector<Record> &records, const uint8_t *path, int depth, std::vector<Record> &sub);
+// With `toward` (and the world bounds) only the nodes that contain that voxel are expanded; every other internal
+// child is emitted as a kKeep record.
+bool extract_subtree(const std::vector<Record> &records, const uint8_t *path, int depth, std::vector<Record> &sub,
+                     const int *toward = nullptr, const int *wmin = nullptr, const int *wmax = nullptr);
 
 // sub: A's new sub-tree, n_sub records, sub[0] = A as an internal record (its child mask may be empty). False (nothing
 // modified) when sub is malformed.
