@@ -201,6 +201,35 @@ def main():
 
     torch.cuda.synchronize(dev)
 
+    # several GPUs: SURVEY 8(e) asks for the rate with AND without the per-frame gather. The timed region above is
+    # the one without (frames stay sharded, or whatever --gather says); here the same K frames are each delivered to
+    # rank 0, double-buffered. Reported beside the headline, not instead of it.
+    delivered = None
+    if world > 1 and args.gather == "final" and not os.environ.get("VRT_BENCH_NO_FRAME_GATHER"):
+        pipe_f = shd.FramePipeline(plan, dev, stage_through_host=via_host, gather="frame", streams=n_streams)
+        for it in range(args.warmup + args.steps):
+            if it == args.warmup:
+                pipe_f.drain()
+                dist.barrier()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+            k, p_rgba, p_id = pipe_f.slot()
+            ctx.dispatch_shard(W, H, args.tile_rows, rank, world, mode, p_rgba, p_id, pipe_f.stream_handle(k))
+            pipe_f.submit(k)
+        pipe_f.drain()
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        ef = time.perf_counter() - t0
+        t = torch.tensor([ef], dtype=torch.float64, device="cpu" if via_host else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ef = float(t.item())
+        same = None
+        if rank == 0:
+            fr, fi = pipe_f.frame_views()
+            same = bool(torch.equal(fr, pipe.frame_views()[0]) and torch.equal(fi, pipe.frame_views()[1]))
+        delivered = {"gather": "frame", "value": round(W * H * args.steps / ef / 1e6, 2), "unit": "Mrays/s",
+                     "ms_per_step": round(ef / args.steps * 1e3, 5), "same_pixels": same}
+
     # one GPU, informational: the same K frames alternating between two streams (no per-launch events; the figure the
     # headline would become if overlapped launches were allowed to blur the per-kernel duration the roofline uses)
     overlapped = None
@@ -308,6 +337,7 @@ def main():
                        "variant": args.variant, "collective_backend": args.backend if world > 1 else None},
             "roofline": roofline,
             "pixels_match_oracle_golden": check,
+            "every_frame_delivered": delivered,
             "overlapped_frames": overlapped,
             "batched_views": batched,
         }
