@@ -378,3 +378,41 @@ def test_edit_patches_answer_like_rebuilt_layouts(V, bounds):
         before = after
     assert patched >= 60, patched
     assert appended / patched < 200, appended / patched          # only the blocks along the path are appended
+
+
+def test_malformed_texel_streams_are_refused_or_laid_out_never_crash(V, product_scenes):
+    """Upload hardening on the host (no device): random byte streams and mutated real ones either lay out within the
+    limits -- and then answer point lookups through the wide cells without leaving their arrays -- or are refused."""
+    rng = np.random.default_rng(4242)
+    tex, _ = product_scenes["monu9"]
+    tex = np.asarray(tex, np.uint8)
+    pts = rng.integers(-1023, 1024, size=(64, 3)).astype(np.int32)
+    laid_out = refused = 0
+    streams = []
+    for n in (0, 4, 8, 12, 40, 400, 4000):
+        streams += [rng.integers(0, 256, size=n, dtype=np.uint8) for _ in range(20)]
+    for _ in range(400):                                   # a real stream with a few bytes, or a run of them, damaged
+        t = tex.copy()
+        k = int(rng.integers(1, 6))
+        pos = rng.integers(0, t.size, size=k)
+        if rng.random() < 0.3:
+            a = int(rng.integers(0, t.size - 64))
+            t[a:a + int(rng.integers(4, 64))] = rng.integers(0, 256, dtype=np.uint8)
+        else:
+            t[pos] = rng.integers(0, 256, size=k, dtype=np.uint8)
+        if rng.random() < 0.2:
+            t = t[: int(rng.integers(4, t.size)) // 4 * 4]   # truncated
+        streams.append(t)
+    for t in streams:
+        try:
+            rec, info = V.build_layout(t)
+        except V.VrtError:
+            refused += 1
+            continue
+        laid_out += 1
+        assert len(rec) == info.n_records and info.max_depth <= 16
+        res = V.wide_find(t, pts)                          # None: no wide form (the record kernels would run)
+        if res is not None:
+            out, (n_nodes, n_roots) = res
+            assert n_roots <= 8
+    assert laid_out > 100 and refused > 10, (laid_out, refused)
