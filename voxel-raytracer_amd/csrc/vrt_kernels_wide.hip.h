@@ -184,19 +184,27 @@ struct Trav {
     // the values are equal, so picking either is the same number.
     struct Axis { bool x, y; };
     static VRT_DEV Axis dda_step(F3 &rp, F3 dir, F3 inv, F3 push, I3 plane) {
-        const float tx = ((float)plane.x - rp.x) * inv.x;
-        const float ty = ((float)plane.y - rp.y) * inv.y;
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        // x and y travel as one packed pair (v_pk_add_f32 / v_pk_mul_f32: the same IEEE operations, ~5 cycles per
+        // pair instead of 8), z alone
+        const f2v pl = {(float)plane.x, (float)plane.y}, r = {rp.x, rp.y}, iv = {inv.x, inv.y}, d = {dir.x, dir.y},
+                  pu = {push.x, push.y};
+        const f2v t2 = (pl - r) * iv;
+        const float tx = t2.x, ty = t2.y;
         const float tz = ((float)plane.z - rp.z) * inv.z;
         const bool xy = tx < ty, xz = tx < tz, yz = ty < tz;
         const bool ax = xy && xz;
         const bool ay = !xy && yz;
         const bool az = !(ax || ay);
         const float t = ax ? tx : (ay ? ty : tz);
-        rp.x = rp.x + dir.x * t; rp.y = rp.y + dir.y * t; rp.z = rp.z + dir.z * t;
-        const float qx = rp.x + push.x, qy = rp.y + push.y, qz = rp.z + push.z;
-        rp.x = ax ? qx : rp.x;
-        rp.y = ay ? qy : rp.y;
-        rp.z = az ? qz : rp.z;
+        const f2v tt = {t, t};
+        const f2v r2 = r + d * tt;
+        const float rz = rp.z + dir.z * t;
+        const f2v q2 = r2 + pu;
+        const float qz = rz + push.z;
+        rp.x = ax ? q2.x : r2.x;
+        rp.y = ay ? q2.y : r2.y;
+        rp.z = az ? qz : rz;
         return Axis{ax, ay};
     }
 
