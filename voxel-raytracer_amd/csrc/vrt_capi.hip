@@ -232,6 +232,7 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     a.lds_records = v.use_lds ? (c->info.n_records < v.lds_cap ? c->info.n_records : v.lds_cap) : 0u;
     a.cells = c->d_cells;
     a.n_roots = c->wide_ok ? (uint32_t)c->wide.roots.size() : 0u;
+    for (int k = 0; k < 3; ++k) a.root0_min[k] = a.n_roots ? c->wide.roots[0].origin[k] : 0;
     for (int i = 0; i < 8; ++i) {
         const bool on = (uint32_t)i < a.n_roots;
         a.root_record[i] = on ? c->wide.roots[(size_t)i].record : 0xffffffffu;

@@ -64,6 +64,7 @@ struct KArgs {
     uint32_t root_record[8];
     uint32_t root_node[8];
     int root_shift[8];
+    int root0_min[3];         // minimum corner of wide root 0's cube (valid when n_roots > 0)
 };
 
 #define VRT_DEV __device__ __forceinline__

@@ -142,7 +142,17 @@ struct Trav {
         uint32_t node = in_node ? w.node : w.anode;
         int s = in_node ? w.s : w.as;
         if (!(in_node || in_anchor)) {
-            if (descend_generic(a, c, p, dpos, w, f, node, s)) return f;
+            // Left the anchor. Inside the cube of wide root 0 (the octant that holds every shipped scene) the
+            // descent from the octree root can only end at that root: start there directly, in the state
+            // descend_generic() would leave behind. Anywhere else walk the records.
+            const int rs = a.root_shift[0];
+            const uint32_t out0 = (uint32_t)((p.x ^ a.root0_min[0]) | (p.y ^ a.root0_min[1]) | (p.z ^ a.root0_min[2])) >> (rs & 31);
+            if (a.n_roots != 0u && out0 == 0u) {
+                node = a.root_node[0]; s = rs;
+                w.s = -1; w.anode = node; w.as = rs;
+            } else if (descend_generic(a, c, p, dpos, w, f, node, s)) {
+                return f;
+            }
         }
         uint2 cell;
         bool go;

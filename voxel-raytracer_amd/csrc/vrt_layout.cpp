@@ -186,7 +186,7 @@ bool collect_roots(const std::vector<Record> &recs, uint32_t rec, const Box &box
         }
         uint32_t node = 0;
         if (!build_wide_node(recs, rec, shift, out, node, why)) return false;
-        out.roots.push_back(WideRoot{rec, node, shift});
+        out.roots.push_back(WideRoot{rec, node, shift, {box.mn[0], box.mn[1], box.mn[2]}});
         return true;
     }
     for (uint32_t ci = 0; ci < 8; ++ci) {

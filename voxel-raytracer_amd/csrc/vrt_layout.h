@@ -62,7 +62,7 @@ bool has_unit_internal_node(const std::vector<Record> &records, const int wmin[3
 // aligned cubes of even log2 side ("roots"); the few levels above them (the reference's world
 // [-1023,1024)^3 is not a power of two) stay in the record array and are walked with explicit AABBs.
 struct WideCell { uint32_t w0, w1; };
-struct WideRoot { uint32_t record; uint32_t node; int shift; };
+struct WideRoot { uint32_t record; uint32_t node; int shift; int origin[3]; };  // origin: minimum corner of the root's cube
 struct WideTree {
     std::vector<WideCell> cells;   // 64 per wide node
     std::vector<WideRoot> roots;
