@@ -210,6 +210,14 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
         std::memcpy(w.cam_pos, views ? views[i].camera_pos : c->cam_pos, sizeof w.cam_pos);
         w.out_rgba = (uint32_t *)(views ? views[i].d_rgba8 : d_rgba);
         w.out_id = (int2 *)(views ? views[i].d_id_dist : d_id);
+        // the shader's lookup at the eye (comp:445-449), same arithmetic: floor(cameraPos * u_voxelScale)
+        int eye[3];
+        for (int k = 0; k < 3; ++k) {
+            const float g = floorf(w.cam_pos[k] * c->params.voxel_scale);
+            // float -> int as the device converts: NaN -> 0, out of range saturates (and is outside any world)
+            eye[k] = g != g ? 0 : (g >= 2147483648.0f ? 2147483647 : (g < -2147483648.0f ? (-2147483647 - 1) : (int)g));
+        }
+        vrt::eye_lookup(c->host_records, c->params.world_min, c->params.world_max, eye, w.eye0, w.eye1);
     }
     a.voxel_scale = c->params.voxel_scale;
     for (int i = 0; i < 3; ++i) {

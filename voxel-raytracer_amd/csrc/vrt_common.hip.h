@@ -31,6 +31,7 @@ struct View {
     float cam_pos[4];
     uint32_t *out_rgba;       // packed R | G<<8 | B<<16 | A<<24
     int2 *out_id;             // (voxelID, dist)
+    uint32_t eye0, eye1;      // raw leaf words of the node that holds the eye (comp:445-449), looked up by the host
 };
 
 // Kernel arguments: passed by value (kernarg segment -> scalar loads, wave-uniform).
@@ -156,7 +157,7 @@ VRT_DEV Decoded decode_leaf(const float *unorm, uint32_t w0, uint32_t w1) {
 }
 
 // One pixel: ray generation (comp:624-641), primary-ray pathTrace, packing of the two outputs.
-// TRAV supplies the traversal: eye_medium(), march(), shadow(). MODE: 0 primary, 1 primary + shadow ray.
+// TRAV supplies the traversal: march(), shadow(). MODE: 0 primary, 1 primary + shadow ray.
 template <int MODE, class TRAV>
 VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, const float *unorm, int px, int py, uint32_t &rgba, int2 &idd) {
     const float kPI = 3.14159265359f;
@@ -175,9 +176,8 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
     int pixel_dist = a.wmax[0] - a.wmin[0];
     F3 gro = scale3(ray_origin, a.voxel_scale);
     // medium at the eye (comp:445-449)
-    uint32_t e0, e1;
-    TRAV::eye_medium(a, tc_, floor_i3(gro), e0, e1);
-    Decoded tvd = decode_leaf(unorm, e0, e1);
+    // medium at the eye (comp:445-449): the same node for every ray of the view, found once by the dispatcher
+    Decoded tvd = decode_leaf(unorm, vw.eye0, vw.eye1);
     float start_iof = (tvd.p[0] > 0.0f && tvd.p[0] < 3.0f) ? tvd.p[0] : 1.0f;
     float inv_len = 1.0f / __builtin_sqrtf(dot3(ray_dir, ray_dir));
     ray_dir = scale3(ray_dir, inv_len);
@@ -190,7 +190,7 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
 
     Hit h;
     // byte form of start_iof for traversals that test media on bytes: r(b) in (0, 3) <=> 1 <= b <= 254, else 1.0 == r(85)
-    const uint32_t eye_b = e1 & 0xffu;
+    const uint32_t eye_b = vw.eye1 & 0xffu;
     const uint32_t iof_byte = (eye_b >= 1u && eye_b <= 254u) ? eye_b : 85u;
     bool hit = TRAV::march(a, tc_, gro, ray_dir, start_iof, iof_byte, h);
     if (!hit) {

@@ -1,7 +1,7 @@
 // vrt_full.hip.h -- VRT_MODE_FULL: the whole of pathTrace (shaders/raytracing.comp:435-622):
 // the 8-deep ray stack with glass reflection/refraction (:546-572), Beer-Lambert absorption
 // (:482-486, :512-516), emission and ambient terms (:574-594), the cosine-weighted diffuse bounce
-// (:596-616) with the PCG-hash RNG (:379-417). The traversal (march / shadow / eye_medium) is the
+// (:596-616) with the PCG-hash RNG (:379-417). The traversal (march / shadow) is the
 // TRAV policy shared with the primary-ray kernels; this file is the shading state machine only.
 //
 // It mirrors the CPU restatement operation for operation (same dot/normalize/cross forms, same
@@ -170,9 +170,7 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
     int voxel_id = 0;
     int pixel_dist = a.wmax[0] - a.wmin[0];
     F3 gro = scale3(ray_origin, a.voxel_scale);
-    uint32_t e0, e1;
-    TRAV::eye_medium(a, tc_, floor_i3(gro), e0, e1);
-    Decoded tv = decode_leaf(unorm, e0, e1);
+    Decoded tv = decode_leaf(unorm, vw.eye0, vw.eye1);  // medium at the eye: looked up once by the dispatcher
     float start_iof = (tv.p[0] > 0.0f && tv.p[0] < 3.0f) ? tv.p[0] : 1.0f;
     float inv_len = 1.0f / __builtin_sqrtf(dot3(ray_dir, ray_dir));
     ray_dir = scale3(ray_dir, inv_len);

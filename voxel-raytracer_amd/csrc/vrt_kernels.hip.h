@@ -172,13 +172,6 @@ struct Trav {
         return find_node(a, c, p, w);
     }
 
-    static VRT_DEV void eye_medium(const KArgs &a, const Ctx &c, I3 p, uint32_t &w0, uint32_t &w1) {
-        Walk w;
-        reset(w);
-        Found f = find_checked(a, c, p, w);
-        w0 = f.w0; w1 = f.w1;
-    }
-
     // One DDA step shared by march() and shadow(): leave the node [mn,mx) through the nearest far plane.
     static VRT_DEV int dda_step(F3 &rp, F3 dir, F3 inv, F3 push, bool px, bool py, bool pz, const Found &n) {
         const float tx = ((px ? (float)n.mx.x : (float)n.mn.x) - rp.x) * inv.x;

@@ -81,12 +81,6 @@ struct Trav {
         return f;
     }
 
-    static VRT_DEV void eye_medium(const KArgs &a, const Ctx &c, I3 p, uint32_t &w0, uint32_t &w1) {
-        Parent par = root_parent(a, c);
-        Found f = find_node(a, c, p, par);
-        w0 = f.w0; w1 = f.w1;
-    }
-
     // hitMarching (comp:248-330)
     static VRT_DEV bool march(const KArgs &a, const Ctx &c, F3 origin, F3 dir, float ray_iof, uint32_t /*iof_byte*/, Hit &h) {
         F3 rp = origin;

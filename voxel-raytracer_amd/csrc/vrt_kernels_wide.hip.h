@@ -40,7 +40,7 @@ struct Found {
 // build time: every leaf word pair a lookup returns has refraction byte 0 when its alpha byte is 0
 // (wide cells: vrt_layout.cpp; record leaves: descend_generic). Nothing downstream can tell: the shader
 // replaces the properties of an alpha-0 voxel before using them (comp:503-504); only the lookup at the
-// eye reads them unconditionally, and eye_medium() goes to the raw records.
+// eye reads them unconditionally, and that one is made by the dispatcher on the raw records (eye_lookup()).
 
 // (int)floor(x) in one instruction
 VRT_DEV int floor_to_int(float x) {
@@ -107,28 +107,6 @@ struct Trav {
             m = rec.x; b = rec.y;
         }
         return true;  // deeper than the uploader allows: treated as empty
-    }
-
-    // The lookup at the eye (comp:445-449) reads the RAW leaf words: startIOF looks at properties[0]
-    // without testing alpha, the one place where the refraction byte of an alpha-0 leaf is observable.
-    // One lookup per ray from a wave-uniform position: plain explicit descent over the record array.
-    static VRT_DEV void eye_medium(const KArgs &a, const Ctx &c, I3 p, uint32_t &w0, uint32_t &w1) {
-        w0 = 0u; w1 = 0u;
-        if (!in_world_u(a, p)) return;
-        uint32_t m = c.root.x, b = c.root.y;
-        I3 mn{a.wmin[0], a.wmin[1], a.wmin[2]}, mx{a.wmax[0], a.wmax[1], a.wmax[2]};
-        for (int i = 0; i < 16; ++i) {
-            const int cx = mn.x + ((mx.x - mn.x) >> 1), cy = mn.y + ((mx.y - mn.y) >> 1), cz = mn.z + ((mx.z - mn.z) >> 1);
-            const bool hx = p.x >= cx, hy = p.y >= cy, hz = p.z >= cz;
-            const uint32_t ci = (hx ? 4u : 0u) | (hy ? 2u : 0u) | (hz ? 1u : 0u);
-            mn = I3{hx ? cx : mn.x, hy ? cy : mn.y, hz ? cz : mn.z};
-            mx = I3{hx ? mx.x : cx, hy ? mx.y : cy, hz ? mx.z : cz};
-            const uint32_t bit = 1u << ci;
-            if (!(m & bit)) return;
-            const uint2 rec = a.nodes[b + (uint32_t)__builtin_popcount(m & (bit - 1u))];
-            if (m & (bit << 8)) { w0 = rec.x; w1 = rec.y; return; }
-            m = rec.x; b = rec.y;
-        }
     }
 
     // octreeFind (comp:137-220) for a point known to be inside the world.

@@ -288,6 +288,32 @@ bool has_unit_internal_node(const std::vector<Record> &records, const int wmin[3
     return false;
 }
 
+void eye_lookup(const std::vector<Record> &recs, const int wmin[3], const int wmax[3], const int p[3], uint32_t &w0,
+                uint32_t &w1) {
+    w0 = w1 = 0u;
+    if (recs.empty()) return;
+    Box b;
+    for (int k = 0; k < 3; ++k) {
+        if (p[k] < wmin[k] || p[k] >= wmax[k]) return;
+        b.mn[k] = wmin[k];
+        b.mx[k] = wmax[k];
+    }
+    uint32_t rec = 0;
+    for (int i = 0; i < 16; ++i) {
+        uint32_t ci = 0;
+        for (int k = 0; k < 3; ++k) {
+            const int mid = b.mn[k] + ((b.mx[k] - b.mn[k]) >> 1);
+            if (p[k] >= mid) ci |= 1u << (2 - k);
+        }
+        b = child_box(b, ci);
+        uint32_t idx = 0;
+        const int kind = child_of(recs, rec, ci, idx);
+        if (kind == kAbsent) return;
+        if (kind == kLeaf) { w0 = recs[idx].w0; w1 = recs[idx].w1; return; }
+        rec = idx;
+    }
+}
+
 size_t stream_texels(const Record *recs, size_t n, uint32_t top) {
     if (top >= n) return 0;
     size_t total = 0;

@@ -81,6 +81,12 @@ bool build_wide(const std::vector<Record> &records, const int wmin[3], const int
 int wide_find_host(const std::vector<Record> &records, const WideTree &wt, const int wmin[3], const int wmax[3],
                    const int p[3], uint32_t &w0, uint32_t &w1, int mn[3], int mx[3]);
 
+// The raw leaf words of the octree node that holds point p (0/0 for empty space or a point outside the world): the
+// lookup the shader makes once per ray at the eye (raytracing.comp:445-449). The eye is the same for every ray of a
+// view, so the dispatcher makes it once on the host and hands the two words to the kernel.
+void eye_lookup(const std::vector<Record> &records, const int wmin[3], const int wmax[3], const int p[3], uint32_t &w0,
+                uint32_t &w1);
+
 // ---------------------------------------------------------------------------------------------
 // Edits without a rebuild. A voxel edit changes the octree below some ancestor A of the voxel and
 // nothing else. When A is an INTERNAL node before and after the edit, the device structures can be
