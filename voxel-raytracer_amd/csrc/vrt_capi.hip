@@ -218,6 +218,12 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
             eye[k] = g != g ? 0 : (g >= 2147483648.0f ? 2147483647 : (g < -2147483648.0f ? (-2147483647 - 1) : (int)g));
         }
         vrt::eye_lookup(c->host_records, c->params.world_min, c->params.world_max, eye, w.eye0, w.eye1);
+        vrt::FirstFind ff;
+        w.first_valid = (c->wide_ok && vrt::first_find(c->wide, c->params.world_min, c->params.world_max, eye, vrt::v3::kAnchorShift, ff)) ? 1 : 0;
+        if (w.first_valid) {
+            w.first_w0 = ff.w0; w.first_w1 = ff.w1; w.first_node = ff.node; w.first_anode = ff.anode;
+            w.first_s = ff.s; w.first_as = ff.as;
+        }
     }
     a.voxel_scale = c->params.voxel_scale;
     for (int i = 0; i < 3; ++i) {

@@ -32,6 +32,9 @@ struct View {
     uint32_t *out_rgba;       // packed R | G<<8 | B<<16 | A<<24
     int2 *out_id;             // (voxelID, dist)
     uint32_t eye0, eye1;      // raw leaf words of the node that holds the eye (comp:445-449), looked up by the host
+    // the primary rays' first lookup (at the eye), made by the host for the wide kernels (vrt_layout.h first_find)
+    uint32_t first_w0, first_w1, first_node, first_anode;
+    int first_s, first_as, first_valid;
 };
 
 // Kernel arguments: passed by value (kernarg segment -> scalar loads, wave-uniform).
@@ -192,7 +195,7 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
     // byte form of start_iof for traversals that test media on bytes: r(b) in (0, 3) <=> 1 <= b <= 254, else 1.0 == r(85)
     const uint32_t eye_b = vw.eye1 & 0xffu;
     const uint32_t iof_byte = (eye_b >= 1u && eye_b <= 254u) ? eye_b : 85u;
-    bool hit = TRAV::march(a, tc_, gro, ray_dir, start_iof, iof_byte, h);
+    bool hit = TRAV::march(a, tc_, gro, ray_dir, start_iof, iof_byte, h, &vw);
     if (!hit) {
         // distanceInMedium is still 0 here, so the absorption branch (comp:482) cannot fire
 #pragma unroll

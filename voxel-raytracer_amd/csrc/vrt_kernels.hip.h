@@ -188,7 +188,8 @@ struct Trav {
     }
 
     // hitMarching (comp:248-330)
-    static VRT_DEV bool march(const KArgs &a, const Ctx &c, F3 origin, F3 dir, float ray_iof, uint32_t iof_byte, Hit &h) {
+    static VRT_DEV bool march(const KArgs &a, const Ctx &c, F3 origin, F3 dir, float ray_iof, uint32_t iof_byte, Hit &h,
+                              const View * = nullptr) {
         (void)ray_iof;
         F3 rp = origin;
         float inv_len = 1.0f / __builtin_sqrtf(dot3(dir, dir));

@@ -82,7 +82,8 @@ struct Trav {
     }
 
     // hitMarching (comp:248-330)
-    static VRT_DEV bool march(const KArgs &a, const Ctx &c, F3 origin, F3 dir, float ray_iof, uint32_t /*iof_byte*/, Hit &h) {
+    static VRT_DEV bool march(const KArgs &a, const Ctx &c, F3 origin, F3 dir, float ray_iof, uint32_t /*iof_byte*/, Hit &h,
+                              const View * = nullptr) {
         F3 rp = origin;
         float inv_len = 1.0f / __builtin_sqrtf(dot3(dir, dir));
         dir = scale3(dir, inv_len);

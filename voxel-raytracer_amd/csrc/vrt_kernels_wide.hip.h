@@ -197,7 +197,9 @@ struct Trav {
     }
 
     // hitMarching (comp:248-330)
-    static VRT_DEV bool march(const KArgs &a, const Ctx &c, F3 origin, F3 dir, float ray_iof, uint32_t iof_byte, Hit &h) {
+    // eye: the view whose eye `origin` is (primary rays): its first lookup was made by the host
+    static VRT_DEV bool march(const KArgs &a, const Ctx &c, F3 origin, F3 dir, float ray_iof, uint32_t iof_byte, Hit &h,
+                              const View *eye = nullptr) {
         (void)ray_iof;
         F3 rp = origin;
         float inv_len = 1.0f / __builtin_sqrtf(dot3(dir, dir));
@@ -210,9 +212,18 @@ struct Trav {
         const F3 sd{sign_c(dir.x), sign_c(dir.y), sign_c(dir.z)};
         const F3 push{sd.x * 0.0001f, sd.y * 0.0001f, sd.z * 0.0001f};  // comp:300-304
         Walk w;
-        reset(w);
         I3 mp = floor_i3_fast(rp);
-        Found cur = find_checked(a, c, mp, dpos, w);
+        Found cur;
+        if (eye && eye->first_valid) {  // wave-uniform
+            w.node = eye->first_node; w.s = eye->first_s; w.anode = eye->first_anode; w.as = eye->first_as; w.last = mp;
+            const int t = (int)(eye->first_w1 >> 24);
+            cur.w0 = eye->first_w0;
+            cur.w1 = eye->first_w1 & 0x00ffffffu;
+            cur.plane = I3{((mp.x >> t) + dpos.x) << t, ((mp.y >> t) + dpos.y) << t, ((mp.z >> t) + dpos.z) << t};
+        } else {
+            reset(w);
+            cur = find_checked(a, c, mp, dpos, w);
+        }
         uint32_t cur_b = cur.w1 & 0xffu;  // medium byte: every Found carries 0 here when alpha == 0
         Axis ax{false, false};
         bool hit = false, go;

@@ -314,6 +314,35 @@ void eye_lookup(const std::vector<Record> &recs, const int wmin[3], const int wm
     }
 }
 
+bool first_find(const WideTree &wide, const int wmin[3], const int wmax[3], const int p[3], int anchor_shift, FirstFind &out) {
+    if (wide.roots.empty()) return false;
+    const WideRoot &r = wide.roots[0];
+    for (int k = 0; k < 3; ++k) {
+        if (p[k] < wmin[k] || p[k] >= wmax[k]) return false;
+        if ((uint32_t)(p[k] ^ r.origin[k]) >> (r.shift & 31)) return false;
+    }
+    uint32_t node = r.node;
+    int s = r.shift;
+    out.anode = node;
+    out.as = s;
+    for (;;) {
+        const int cs = s - 2;
+        const uint32_t ci = ((((uint32_t)p[0] >> cs) & 3u) << 4) | ((((uint32_t)p[1] >> cs) & 3u) << 2) | (((uint32_t)p[2] >> cs) & 3u);
+        const WideCell c = wide.cells[(size_t)node * 64 + ci];
+        if (!(c.w1 & kWideInternal)) {
+            out.w0 = c.w0;
+            out.w1 = c.w1;
+            out.node = node;
+            out.s = s;
+            return true;
+        }
+        node = c.w0;
+        s = cs;
+        if (cs == anchor_shift) { out.anode = node; out.as = cs; }
+        if (cs < 2 || (size_t)node * 64 + 63 >= wide.cells.size()) return false;
+    }
+}
+
 size_t stream_texels(const Record *recs, size_t n, uint32_t top) {
     if (top >= n) return 0;
     size_t total = 0;

@@ -87,6 +87,13 @@ int wide_find_host(const std::vector<Record> &records, const WideTree &wt, const
 void eye_lookup(const std::vector<Record> &records, const int wmin[3], const int wmax[3], const int p[3], uint32_t &w0,
                 uint32_t &w1);
 
+// The first lookup of every primary ray of a view is made at the eye too: the same point, hence the same wide-layout
+// walk, for every ray. first_find() makes it once on the host in the form the wide kernels keep it (the cell found
+// and the restart state: current wide node, anchor node, their log2 sides). False when the wide kernels would not
+// start at wide root 0 (no wide layout, eye outside the world or outside that root's cube): they then look it up.
+struct FirstFind { uint32_t w0, w1, node, anode; int s, as; };
+bool first_find(const WideTree &wide, const int wmin[3], const int wmax[3], const int p[3], int anchor_shift, FirstFind &out);
+
 // ---------------------------------------------------------------------------------------------
 // Edits without a rebuild. A voxel edit changes the octree below some ancestor A of the voxel and
 // nothing else. When A is an INTERNAL node before and after the edit, the device structures can be
