@@ -269,8 +269,9 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     const hipEvent_t ev1 = prof ? c->prof_events[2 * c->prof_count + 1] : nullptr;
     hipError_t e;
     if (mode == VRT_MODE_FULL) {
-        // the full path tracer is instantiated for the default traversal and for the explicit-AABB baseline only
-        if (v.trav == 3) e = launch_one<2, vrt::v3::Trav, 8, 256, 1>(a, vs, (int)grid, 0, s, ev0, ev1);
+        // the full path tracer is instantiated for the default traversal and for the explicit-AABB baseline only; five
+        // waves per SIMD (96 VGPRs, no extra spills) measured 8-10 % faster than the unconstrained 105-VGPR build
+        if (v.trav == 3) e = launch_one<2, vrt::v3::Trav, 8, 256, 5>(a, vs, (int)grid, 0, s, ev0, ev1);
         else if (v.trav == 2) e = launch_one<2, vrt::v2::Trav<false>, 8, 256, 1>(a, vs, (int)grid, 0, s);
         else e = launch_one<2, vrt::v1::Trav<false>, 8, 256, 1>(a, vs, (int)grid, 0, s);
     } else {
