@@ -94,6 +94,7 @@ struct vrt_ctx {
     bool wide_ok = false;
     vrt::WideTree wide;
     uint2 *d_cells = nullptr;
+    uint32_t *d_roots = nullptr;  // 16 words: record and wide node of each wide root (vrt_common.hip.h KArgs::root_table)
     size_t cells_capacity = 0;
     std::string err;
 };
@@ -247,12 +248,9 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     a.cells = c->d_cells;
     a.n_roots = c->wide_ok ? (uint32_t)c->wide.roots.size() : 0u;
     for (int k = 0; k < 3; ++k) a.root0_min[k] = a.n_roots ? c->wide.roots[0].origin[k] : 0;
-    for (int i = 0; i < 8; ++i) {
-        const bool on = (uint32_t)i < a.n_roots;
-        a.root_record[i] = on ? c->wide.roots[(size_t)i].record : 0xffffffffu;
-        a.root_node[i] = on ? c->wide.roots[(size_t)i].node : 0u;
-        a.root_shift[i] = on ? c->wide.roots[(size_t)i].shift : 0;
-    }
+    a.root_table = c->d_roots;
+    a.root0_node = a.n_roots ? c->wide.roots[0].node : 0u;
+    a.root0_shift = a.n_roots ? c->wide.roots[0].shift : 0;
 
     const int th = 64 / v.tw;
     const long tiles = (long)((width + v.tw - 1) / v.tw) * (long)((n_rows + th - 1) / th);
@@ -348,6 +346,7 @@ void vrt_destroy(vrt_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_nodes) (void)hipFree(c->d_nodes);
     if (c->d_cells) (void)hipFree(c->d_cells);
+    if (c->d_roots) (void)hipFree(c->d_roots);
     if (c->d_rgba) (void)hipFree(c->d_rgba);
     if (c->d_id) (void)hipFree(c->d_id);
     if (c->d_shown) (void)hipFree(c->d_shown);
@@ -480,6 +479,19 @@ int vrt_upload_records(vrt_ctx *c, const uint32_t *records, size_t n_records, ui
 namespace {
 // (re)derives what depends on the world bounds: whether the wide layout can be used, and the layout itself on the
 // device. Called lazily by the dispatcher and by the patch entry points.
+// the wide roots' table on the device; blocking (callers have synchronised the device or run before any dispatch)
+int upload_roots(vrt_ctx *c) {
+    uint32_t t[16];
+    for (int i = 0; i < 8; ++i) {
+        const bool on = c->wide_ok && (size_t)i < c->wide.roots.size();
+        t[i] = on ? c->wide.roots[(size_t)i].record : 0xffffffffu;
+        t[8 + i] = on ? c->wide.roots[(size_t)i].node : 0u;
+    }
+    if (!c->d_roots) VRT_HIP(c, hipMalloc((void **)&c->d_roots, sizeof t));
+    VRT_HIP(c, hipMemcpy(c->d_roots, t, sizeof t, hipMemcpyHostToDevice));
+    return VRT_OK;
+}
+
 int ensure_analysis(vrt_ctx *c) {
     if (c->analysis_valid) return VRT_OK;
     c->unit_internal = vrt::has_unit_internal_node(c->host_records, c->params.world_min, c->params.world_max);
@@ -500,6 +512,11 @@ int ensure_analysis(vrt_ctx *c) {
         VRT_HIP(c, hipDeviceSynchronize());
         if (!c->wide.cells.empty())
             VRT_HIP(c, hipMemcpy(c->d_cells, c->wide.cells.data(), c->wide.cells.size() * sizeof(vrt::WideCell), hipMemcpyHostToDevice));
+    }
+    VRT_HIP(c, hipDeviceSynchronize());
+    {
+        const int rr = upload_roots(c);
+        if (rr) return rr;
     }
     c->analysis_valid = true;
     return VRT_OK;
@@ -593,6 +610,10 @@ int vrt_patch_apply(vrt_ctx *c, const vrt_patch *patch, const uint32_t *subtree_
                 if (c->wide.cells.size() > from)
                     VRT_HIP(c, hipMemcpy(c->d_cells + from, c->wide.cells.data() + from, (c->wide.cells.size() - from) * sizeof(vrt::WideCell),
                                          hipMemcpyHostToDevice));
+                if (site.root_index >= 0) {
+                    const int rr = upload_roots(c);
+                    if (rr) return rr;
+                }
                 if (rg.cell_repointed) {
                     const size_t at = (size_t)site.parent_node * 64 + site.parent_cell;
                     VRT_HIP(c, hipMemcpy(c->d_cells + at, c->wide.cells.data() + at, sizeof(vrt::WideCell), hipMemcpyHostToDevice));

@@ -65,9 +65,11 @@ struct KArgs {
     // wide layout (vrt_layout.h): 64 cells per node; roots = octree records where a wide tree starts
     const uint2 *cells;
     uint32_t n_roots;
-    uint32_t root_record[8];
-    uint32_t root_node[8];
-    int root_shift[8];
+    // wide roots: [0..7] octree record of each root, [8..15] its wide node (device memory; read only by the record
+    // walk that a lookup outside wide root 0 takes). Root 0's node and log2 side also travel by value.
+    const uint32_t *root_table;
+    uint32_t root0_node;
+    int root0_shift;
     int root0_min[3];         // minimum corner of wide root 0's cube (valid when n_roots > 0)
 };
 

@@ -79,9 +79,13 @@ struct Trav {
                 const int sh = 31 - __builtin_clz((unsigned)sx);
                 if (!(sh & 1)) {
                     bool found = false;
+                    // the table is read here, on the rare path, and nowhere else: the empty asm keeps the compiler from
+                    // hoisting sixteen scalar loads (and their registers) out of the traversal loop
+                    const uint32_t *roots = a.root_table;
+                    asm volatile("" : "+s"(roots));
 #pragma unroll
                     for (int k = 0; k < 8; ++k)
-                        if ((uint32_t)k < a.n_roots && a.root_record[k] == ridx) { node = a.root_node[k]; found = true; }
+                        if ((uint32_t)k < a.n_roots && roots[k] == ridx) { node = roots[8 + k]; found = true; }
                     if (found) {
                         s = sh;
                         w.anode = node; w.as = sh;
@@ -123,10 +127,10 @@ struct Trav {
             // Left the anchor. Inside the cube of wide root 0 (the octant that holds every shipped scene) the
             // descent from the octree root can only end at that root: start there directly, in the state
             // descend_generic() would leave behind. Anywhere else walk the records.
-            const int rs = a.root_shift[0];
+            const int rs = a.root0_shift;
             const uint32_t out0 = (uint32_t)((p.x ^ a.root0_min[0]) | (p.y ^ a.root0_min[1]) | (p.z ^ a.root0_min[2])) >> (rs & 31);
             if (a.n_roots != 0u && out0 == 0u) {
-                node = a.root_node[0]; s = rs;
+                node = a.root0_node; s = rs;
                 w.s = -1; w.anode = node; w.as = rs;
             } else if (descend_generic(a, c, p, dpos, w, f, node, s)) {
                 return f;
