@@ -63,14 +63,14 @@ class ShardPlan:
         return idx.reshape(-1).to(device)
 
 
-def gather_frame(plan, local, gathered, store, index, group=None, stage_through_host=False):
+def gather_frame(plan, local, gathered, store, index, group=None, stage_through_host=False, collective=None):
     """Gathers every rank's compact buffer to rank 0 and scatters the rows into the frame store there.
 
     local: this rank's buffer [words]; gathered: rank 0's [world, words] tensor (None elsewhere);
     store/index: rank 0's frame store and scatter index (None elsewhere).
     stage_through_host: for backends without device-tensor gather (gloo rehearsals of the N>1 path on a
     box whose ranks share one GPU): the collective runs on host copies."""
-    if plan.world > 1:
+    if plan.world > 1 if collective is None else collective:   # collective=True: call the backend even with one rank
         if stage_through_host and local.is_cuda:
             host = local.cpu()
             recv = [torch.empty_like(host) for _ in range(plan.world)] if plan.rank == 0 else None
@@ -104,16 +104,18 @@ class FramePipeline:
     21.8 MB x (N-1)/N per frame through rank 0's xGMI links.
     """
 
-    def __init__(self, plan, device, group=None, stage_through_host=False, gather="final", streams=1):
+    def __init__(self, plan, device, group=None, stage_through_host=False, gather="final", streams=1, collective=None):
         if gather not in ("final", "frame"):
             raise ValueError("gather must be 'final' or 'frame'")
         if streams not in (1, 2):
             raise ValueError("streams must be 1 or 2")
         self.plan, self.group, self.via_host, self.mode = plan, group, stage_through_host, gather
+        # collective=True runs the gathers through the backend even when there is a single rank (tools/rccl_rehearsal.py)
+        self.dist = plan.world > 1 if collective is None else bool(collective)
         self.local = [plan.local_buffer(device) for _ in range(2)]
         root = plan.rank == 0
         n_recv = 2 if gather == "frame" else 1
-        self.gathered = [plan.gather_buffer(device) if (root and plan.world > 1) else None for _ in range(n_recv)]
+        self.gathered = [plan.gather_buffer(device) if (root and self.dist) else None for _ in range(n_recv)]
         self.store = plan.frame_store(device) if root else None
         self.index = plan.scatter_index(device) if root else None
         self.pending = [None, None]   # per slot: None | "resident" | async work handle
@@ -147,11 +149,11 @@ class FramePipeline:
     def submit(self, k):
         """call after the trace of the frame in slot k has been enqueued on stream_handle(k)"""
         plan = self.plan
-        if plan.world == 1 or self.mode == "final":
+        if not self.dist or self.mode == "final":
             self.pending[k] = "resident"
         elif self.via_host and self.local[k].is_cuda:
             self._join(k)
-            gather_frame(plan, self.local[k], self.gathered[k], self.store, self.index, self.group, True)
+            gather_frame(plan, self.local[k], self.gathered[k], self.store, self.index, self.group, True, self.dist)
             self.pending[k] = None
         else:
             recv = list(self.gathered[k].unbind(0)) if plan.rank == 0 else None
@@ -183,7 +185,7 @@ class FramePipeline:
             if final:
                 self._join(k)
                 gather_frame(plan, self.local[k], self.gathered[0], self.store, self.index, self.group,
-                             self.via_host)
+                             self.via_host, self.dist)
                 self._release(k)
             return
         h.wait()
