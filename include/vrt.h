@@ -99,7 +99,6 @@ typedef struct vrt_patch {
 int vrt_patch_plan(vrt_ctx *ctx, int x, int y, int z, int max_depth, vrt_patch *out);
 int vrt_patch_apply(vrt_ctx *ctx, const vrt_patch *patch, const uint32_t *subtree_records, size_t n_records);
 
-
 /* EXTENSION (not a reference interface): upload the device record array itself -- 2 x uint32 per record,
  * level order, root first; internal: {child_mask | leaf_mask << 8, first child index}, leaf:
  * {R | G<<8 | B<<16 | alpha<<24, refr | illum<<8 | k<<16} -- as vrth_world_records() (vrt_host.h) emits it
@@ -172,13 +171,13 @@ int vrt_denoise_host(vrt_ctx *ctx, int width, int height, const uint8_t *rgba8, 
 int vrt_dispatch_frame(vrt_ctx *ctx, int width, int height, int mode, uint8_t *out_shown_rgba8, uint8_t *out_rgba8,
                        int32_t *out_id_dist);
 
-/* Per-launch timing of the dispatches that follow: a hipEvent pair is recorded
- * around each kernel launch, on the stream it is launched on, for up to
- * max_launches launches (0 switches it off). vrt_profile_read waits for the
- * recorded launches, writes their durations (ms) and returns how many. */
+/* Per-launch timing of the dispatches that follow: a hipEvent pair is attached
+ * to the kernel's dispatch packet (hipExtLaunchKernel), so it reads the kernel's
+ * own begin-to-end time on the stream it runs on, for up to max_launches
+ * launches (0 switches it off). vrt_profile_read waits for the recorded
+ * launches, writes their durations (ms) and returns how many. */
 int vrt_set_profiling(vrt_ctx *ctx, int max_launches);
-/* bracket only every `every`-th launch (default 1): an event pair keeps consecutive launches from
- * overlapping, so sampling leaves the timed region closer to an unprofiled run */
+/* time only every `every`-th launch (default 1): timing every launch costs a few percent of the frame rate */
 int vrt_set_profiling_stride(vrt_ctx *ctx, int every);
 int vrt_profile_read(vrt_ctx *ctx, float *ms_out, int cap);
 
