@@ -1,7 +1,12 @@
-// octree.hpp -- sparse voxel octree host API (reference: include/octree.hpp:15-30).
-// Same node type and entry points as the reference so main.cpp-style callers
-// compile unchanged; the implementation (voxel-raytracer_amd/csrc/host/octree.cpp)
-// is this repository's own and produces a byte-identical octree_texture() stream.
+// octree.hpp -- the sparse voxel octree of the host API. Node type and entry points are named as in the reference's
+// include/octree.hpp so main.cpp-style callers compile unchanged; the implementation
+// (voxel-raytracer_amd/csrc/host/octree.cpp) is this repository's own and flattens to a byte-identical texel stream.
+//
+// Shape of the tree: a node covers the half-open integer box [left_bot_back, right_top_front); it is either a leaf
+// (children == NULL; has_voxel says whether `voxel` is meaningful) or has exactly eight children, child
+// i = (x >= mid) * 4 + (y >= mid) * 2 + (z >= mid) with mid = min + (max - min) / 2 per axis. Inserting splits all
+// the way down to unit cells and, on the way back up, folds eight equal leaves into their parent, so uniform regions
+// are single large leaves. Every node is heap-allocated; octree_delete() releases a whole tree.
 #ifndef VRT_OCTREE_HPP
 #define VRT_OCTREE_HPP
 #include <stdint.h>
@@ -14,21 +19,34 @@ extern "C" {
 }
 
 typedef struct _octree {
-    Voxel_Object voxel;
+    Voxel_Object voxel;                       // the leaf's content; for a folded region coord = the box's minimum corner
     bool has_voxel;
-    struct _octree **children, *parent;  // children: NULL or exactly 8 entries
-    IVector3 left_bot_back, right_top_front;  // half-open AABB [min, max)
+    struct _octree **children, *parent;       // children: NULL or an array of exactly 8 (entries may be empty leaves)
+    IVector3 left_bot_back, right_top_front;  // [min, max)
 } Octree;
 
+// an empty node without a box / a node covering [left_bot_back, right_top_front) under `parent` (NULL for a root)
 Octree *octree_new(void);
 Octree *octree_create(Octree *parent, IVector3 left_bot_back, IVector3 right_top_front);
+
+// Places (or replaces) one voxel; cells outside the root's box are ignored.
 void octree_insert(Octree *tree, Voxel_Object voxel);
+// The voxel stored for `coord`, or a Voxel_Object whose colour is 0 when the cell is empty or outside.
 Voxel_Object octree_find(Octree *tree, IVector3 coord);
-Octree *octree_ray_cast(Octree *root, Ray ray, Vector3 box_min, Vector3 box_max);
-// calloc'd texel bytes (4 per texel), *arr_size = byte count; NULL/0 for an empty tree. Caller frees.
-uint8_t *octree_texture(Octree *tree, size_t *arr_size, size_t tex_dim);
-size_t _octree_texel_size(Octree *tree);
+// Empties one cell (splitting a folded region if needed) and folds what can be folded again.
 void octree_remove(Octree *tree, IVector3 coord);
+// Walks a ray through the tree restricted to [box_min, box_max) and returns the first non-empty leaf it enters,
+// or NULL. The direction need not be normalised. (CPU picking: the GPU path does its own traversal.)
+Octree *octree_ray_cast(Octree *root, Ray ray, Vector3 box_min, Vector3 box_max);
+
+// Flattening for the GPU. _octree_texel_size() is the number of 4-byte texels the tree needs -- one header per
+// internal node, one pointer per present child, two per leaf -- and tex_dim = ceil(cbrt(that)) is the side of the
+// 3D texture the reference stores them in. octree_texture() returns a calloc'd array of 4 * texels bytes (depth-first,
+// root header at texel 0; format in SURVEY.md Appendix A) and its size in *arr_size, or NULL / 0 for an empty tree.
+// The caller frees it. Streams are limited to 2^23 texels by their 23-bit child pointers.
+size_t _octree_texel_size(Octree *tree);
+uint8_t *octree_texture(Octree *tree, size_t *arr_size, size_t tex_dim);
+
 void octree_delete(Octree *tree);
 
 #endif

@@ -1,4 +1,15 @@
-// voxReader.hpp -- MagicaVoxel .vox loader of the host API (reference: include/voxReader.hpp:14).
+// voxReader.hpp -- MagicaVoxel .vox import of the host API (entry point named as in the reference's
+// include/voxReader.hpp; implementation: voxel-raytracer_amd/csrc/host/voxReader.cpp).
+//
+// load_vox_file() reads a version-150/200 file: MAIN { SIZE, XYZI, RGBA, optional scene graph nTRN / nGRP / nSHP }.
+//   * Without a scene graph every model is placed "raw": file voxel (x, y, z) -- z up -- lands in world cell
+//     (offsetX + x, offsetY + z, offsetZ + y) -- y up.
+//   * With a scene graph the nTRN translations and rotation bytes are composed down the tree and each model is
+//     centred on its node (size / 2 subtracted before rotation, rounded to the nearest integer afterwards).
+//   * Colours come from the file's RGBA chunk (palette[colorIndex - 1]) or, if there is none, from MagicaVoxel's
+//     default palette; every voxel receives the material voxels[0].
+// Returns false (and says why on stderr) for a missing file, a bad magic number or a chunk that runs past the end
+// of the file; voxels read before the fault stay inserted. Progress messages appear only with VRT_VERBOSE=1.
 #ifndef VRT_VOXREADER_HPP
 #define VRT_VOXREADER_HPP
 extern "C" {
@@ -7,8 +18,9 @@ extern "C" {
 #include <octree.hpp>
 #include <voxel.hpp>
 
-// Material / colour tables the reference's application defines (src/main.cpp:220-259)
-// and its loader reads (voxels[0] is the material given to every loaded voxel).
+// The application's material and colour tables (the reference defines them in src/main.cpp). The host library
+// carries weak defaults -- voxels[0] = {3.0, 0.0, 0.0}, the reference's first entry -- which a definition in the
+// application overrides.
 extern Voxel voxels[];
 extern ColorRGBA voxelColors[];
 

@@ -1,7 +1,7 @@
 // Address/UB-sanitizer harness for the host library's .vox loader, octree builder and flattener on damaged files. CPU only.
 //   cd voxel-raytracer_amd/csrc/host && gcc -O1 -g -fsanitize=address,undefined -I../../../include -c vmm5.c color.c && \
 //   g++ -std=c++17 -O1 -g -fsanitize=address,undefined -I../../../include ../../../tools/asan_vox_harness.cpp octree.cpp \
-//       voxReader.cpp voxel.cpp vmm5.o color.o -o /tmp/asan_vox && /tmp/asan_vox ../../../tests/golden/maps/monu9.vox
+//       voxReader.cpp vmm5.o color.o -o /tmp/asan_vox && /tmp/asan_vox ../../../tests/golden/maps/monu9.vox
 // Round 1: 400 damaged files (184 loaded, 216 refused), no sanitizer report.
 #include <octree.hpp>
 #include <voxReader.hpp>

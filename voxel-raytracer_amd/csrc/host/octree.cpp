@@ -361,3 +361,10 @@ void octree_delete(Octree *tree) {
     }
     if (!in_parent_block(tree)) free(tree);
 }
+
+// ---- voxel value helpers (include/voxel.hpp) -------------------------------------------------------------------
+Voxel_Object VoxelObjCreate(Voxel voxel, ColorRGBA color, IVector3 coord) { return Voxel_Object{coord, color, voxel}; }
+
+bool voxel_compare(Voxel a, Voxel b) { return a.refraction == b.refraction && a.illumination == b.illumination; }  // k: not compared
+
+bool voxel_obj_compare(Voxel_Object a, Voxel_Object b) { return ivec3_equal_vec(a.coord, b.coord) && voxel_compare(a.voxel, b.voxel); }
