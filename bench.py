@@ -27,7 +27,8 @@ POSES = {  # framing poses of SURVEY.md 8(d): x, y, z, yaw, pitch
     "terrain": (512.5, 420.5, 1000.5, -90.0, -20.0),  # config 4: procedural 1024^2 heightfield shell
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_EVERY = int(os.environ.get("VRT_BENCH_PROFILE_EVERY", "8"))  # every n-th launch of the timed region carries events
+# every n-th launch of the timed region carries events (odd: no beat with the scheduler's measuring launches, every 16th)
+PROFILE_EVERY = int(os.environ.get("VRT_BENCH_PROFILE_EVERY", "7"))
 
 
 def metric_name():
@@ -116,6 +117,9 @@ def main():
                     help="one GPU: after the timed region also time the same frames alternating between two streams "
                          "(overlapped_frames) and four per launch (batched_views). Off by default so that a rocprofv3 "
                          "kernel trace of the default command holds the timed region's launches only")
+    ap.add_argument("--sched-period", type=int, default=16,
+                    help="feedback tile scheduling (vrt_set_tile_scheduling): every n-th launch of a shape measures its tiles "
+                         "and the following ones start them heaviest first; 0 = off (row-major starts). 16 is the library default")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured path); gloo only rehearses the N>1 code path on a "
                          "box whose ranks share one GPU (collective staged through host memory)")
@@ -162,6 +166,7 @@ def main():
 
     ctx = V.Context(dev_index)
     ctx.set_variant(args.variant)
+    ctx.set_tile_scheduling(args.sched_period)
     ctx.upload_octree(tex, dim)
     ctx.set_camera(ip, iv, cp)
 
@@ -184,7 +189,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    # every 8th launch of the timed region carries a hipEvent pair on its stream (a pair around EVERY launch keeps
+    # every 7th launch of the timed region carries a hipEvent pair on its stream (a pair around EVERY launch keeps
     # consecutive launches from overlapping and costs ~6 % of the frame rate)
     ctx.set_profiling(0 if args.no_kernel_events else args.steps, every=PROFILE_EVERY)
     t0 = time.perf_counter()
@@ -333,7 +338,7 @@ def main():
                            "assembled inside the timed region" if args.gather == "final" else
                            "every frame gathered to rank 0 inside the timed region, double-buffered (gather of frame i "
                            "overlaps trace of frame i+1)"),
-                       "gather": args.gather, "streams": n_streams,
+                       "gather": args.gather, "streams": n_streams, "tile_scheduling_period": args.sched_period,
                        "variant": args.variant, "collective_backend": args.backend if world > 1 else None},
             "roofline": roofline,
             "pixels_match_oracle_golden": check,

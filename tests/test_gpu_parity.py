@@ -417,6 +417,86 @@ def test_row_sharding_properties_at_full_size(ctx, V, golden, product_scenes):
     assert np.array_equal(again_rgba, full_rgba) and np.array_equal(again_id, full_id)
 
 
+def test_feedback_tile_scheduling_never_changes_pixels(V, O, product_scenes):
+    """vrt_set_tile_scheduling: launches that repeat a shape start their tiles in an order derived from measured tile
+    times. Whatever that order is -- fresh, stale after the camera moved or the scene changed, re-derived on every
+    launch -- each frame must equal the oracle's, and the order must be a permutation of the launch's workgroups.
+    Covers the three scheduled kernel flavours (measure, ordered, ordered + measure), a tile count that is not a
+    multiple of the workgroup's four tiles, both modes, a row shard and two streams with their own states."""
+    import torch
+    tex, dim = product_scenes["dragon"]
+    c = V.Context(0)
+    try:
+        c.upload_octree(tex, dim)
+        poses = [(63.5, 60.5, 140.5, -90.0, -10.0), (70.5, 58.5, 120.5, -95.0, -8.0), (20.5, 90.5, 100.5, -60.0, -30.0)]
+        for (W, H), mode, period in [((1016, 520), 0, 2), ((1024, 512), 1, 3), ((1016, 520), 0, 1)]:
+            n_wg = (((W + 7) // 8) * ((H + 7) // 8) + 3) // 4
+            assert n_wg >= 2048
+            c.set_tile_scheduling(period)
+            seen_orders = []
+            for k in range(7):
+                pose = poses[(k // 2) % len(poses)]          # the camera moves every other frame: orders go stale
+                ip, iv, cp, _ = V.camera_block(pose[:3], pose[3], pose[4], W, H)
+                c.set_camera(ip, iv, cp)
+                rgba, idd = c.dispatch(W, H, mode)
+                if k % 2 == 0:
+                    ref_rgba, ref_id, _ = _oracle_frame(O, tex, dim, (ip, iv, cp), W, H, mode)
+                _assert_same(rgba, ref_rgba, f"{W}x{H} mode {mode} period {period} frame {k} rgba8")
+                _assert_same(idd, ref_id, f"{W}x{H} mode {mode} period {period} frame {k} id/dist")
+                o = c.sched_order()
+                assert o.size == n_wg and np.array_equal(np.sort(o), np.arange(n_wg, dtype=np.uint32)), (W, H, k)
+                seen_orders.append(o)
+            assert any(not np.array_equal(o, np.arange(n_wg)) for o in seen_orders)   # it does reorder
+            # switched off: row-major starts again, same pixels
+            c.set_tile_scheduling(0)
+            rgba, idd = c.dispatch(W, H, mode)
+            _assert_same(rgba, ref_rgba, "scheduling off rgba8")
+            _assert_same(idd, ref_id, "scheduling off id/dist")
+        # a scene edit under a live order: the stale order is still a permutation
+        c.set_tile_scheduling(2)
+        W, H = 1024, 512
+        ip, iv, cp, _ = V.camera_block(poses[0][:3], poses[0][3], poses[0][4], W, H)
+        c.set_camera(ip, iv, cp)
+        for _ in range(3):
+            c.dispatch(W, H, 0)
+        tex2, dim2 = product_scenes["monu9"]
+        c.upload_octree(tex2, dim2)
+        ref_rgba, ref_id, _ = _oracle_frame(O, tex2, dim2, (ip, iv, cp), W, H, 0)
+        for k in range(3):
+            rgba, idd = c.dispatch(W, H, 0)
+            _assert_same(rgba, ref_rgba, f"after scene change frame {k} rgba8")
+            _assert_same(idd, ref_id, f"after scene change frame {k} id/dist")
+        # two streams alternating frames of one shape (bench.py's pipeline) and a 2-way row shard: a state per stream
+        c.upload_octree(tex, dim)
+        W, H = 1920, 1080
+        ip, iv, cp, _ = V.camera_block(poses[0][:3], poses[0][3], poses[0][4], W, H)
+        c.set_camera(ip, iv, cp)
+        c.set_tile_scheduling(0)
+        full_rgba, full_id = c.dispatch(W, H, 1)
+        c.set_tile_scheduling(2)
+        dev = torch.device("cuda:0")
+        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        for n_shards in (1, 2):
+            rows = [V.shard_row_indices(H, 8, s, n_shards) for s in range(n_shards)]
+            bufs = [[(torch.zeros((len(rows[s]), W), dtype=torch.int32, device=dev),
+                      torch.zeros((len(rows[s]), W, 2), dtype=torch.int32, device=dev)) for s in range(n_shards)] for _ in range(2)]
+            torch.cuda.synchronize()
+            for k in range(10):
+                for s in range(n_shards):
+                    r, i = bufs[k & 1][s]
+                    c.dispatch_shard(W, H, 8, s, n_shards, 1, r.data_ptr(), i.data_ptr(), streams[k & 1].cuda_stream)
+            torch.cuda.synchronize()
+            for b in bufs:
+                for s in range(n_shards):
+                    assert np.array_equal(b[s][0].cpu().numpy().view(np.uint8).reshape(-1, W, 4), full_rgba[rows[s]]), (n_shards, s)
+                    assert np.array_equal(b[s][1].cpu().numpy(), full_id[rows[s]]), (n_shards, s)
+            for st in streams:
+                o = c.sched_order(st.cuda_stream)
+                assert o.size and np.array_equal(np.sort(o), np.arange(o.size, dtype=np.uint32))
+    finally:
+        c.close()
+
+
 def test_error_behaviour(V):
     c = V.Context(0)
     with pytest.raises(V.VrtError, match="no octree"):

@@ -481,6 +481,22 @@ class Context:
     def denoise_device(self, width, height, d_rgba, d_id, d_out, stream=None):
         self._chk(self._L.vrt_denoise(self._h, width, height, d_rgba, d_id, d_out, stream))
 
+    def set_tile_scheduling(self, period):
+        """Feedback scheduling of the tracing kernel's tiles (vrt_set_tile_scheduling): 0 = off, default 16."""
+        self._L.vrt_set_tile_scheduling.argtypes = [C.c_void_p, C.c_int]
+        self._chk(self._L.vrt_set_tile_scheduling(self._h, period))
+
+    def sched_order(self, stream=None, cap=1 << 20):
+        """The scheduler's current workgroup order for the shape last launched on `stream` (vrt_debug_sched_order);
+        empty until an order has been derived."""
+        self._L.vrt_debug_sched_order.restype = C.c_long
+        self._L.vrt_debug_sched_order.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        buf = np.zeros(cap, np.uint32)
+        n = self._L.vrt_debug_sched_order(self._h, stream, buf.ctypes.data, cap)
+        if n < 0:
+            self._chk(n)
+        return buf[:min(n, cap)].copy()
+
     def set_denoise_variant(self, v):
         """Pixels per lane of the display-pass kernel: 0 = two (default), 1 = one."""
         self._chk(self._L.vrt_debug_set_denoise_variant(self._h, v))

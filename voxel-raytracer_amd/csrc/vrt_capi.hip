@@ -59,6 +59,21 @@ constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
 }  // namespace
 
+// Feedback scheduling state of one launch shape on one stream. Launches that repeat a shape on a stream (the frames of
+// a camera path) share it: every sched_period-th of them also records what each tile cost, tile_order_kernel turns that
+// into a heaviest-first workgroup order on the same stream, and the launches that follow start their workgroups in
+// that order. The order is a permutation whatever the costs are, so a stale one (camera moved, scene edited) only
+// loses speed, never pixels; states are per stream because the order buffer is rewritten in stream order.
+struct SchedState {
+    hipStream_t stream = nullptr;
+    int width = 0, n_rows = 0, row0 = 0, row_stride = 0, tile_rows = 0, mode = 0;
+    uint32_t n_tiles = 0, n_wg = 0;
+    uint32_t *d_cost = nullptr, *d_order = nullptr;
+    bool valid = false;        // d_order holds an order
+    uint64_t launches = 0;
+    uint64_t last_use = 0;
+};
+
 struct vrt_ctx {
     int device = 0;
     int n_cus = 256;
@@ -96,6 +111,12 @@ struct vrt_ctx {
     uint2 *d_cells = nullptr;
     uint32_t *d_roots = nullptr;  // 16 words: record and wide node of each wide root (vrt_common.hip.h KArgs::root_table)
     size_t cells_capacity = 0;
+    // feedback scheduling of the default kernel (see SchedState)
+    int sched_period = 16;                   // every n-th launch of a shape measures its tiles; 0 = off
+    std::vector<SchedState> sched;
+    const uint32_t *dbg_wg_order = nullptr;  // vrt_debug_set_tile_order: caller-owned buffers instead of the scheduler's
+    uint32_t *dbg_tile_cost = nullptr;
+    bool dbg_sched = false;
     std::string err;
 };
 
@@ -113,7 +134,7 @@ int fail(vrt_ctx *c, int code, const std::string &msg) {
             return fail((c), VRT_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-template <int MODE, class TRAV, int TW, int BLOCK, int WPE, bool PERSIST = false>
+template <int MODE, class TRAV, int TW, int BLOCK, int WPE, bool PERSIST = false, int SCHED = 0>
 // ev0/ev1 (both or neither): events attached to THIS dispatch packet (hipExtLaunchKernel), so their elapsed time is
 // the kernel's own begin-to-end time, as a profiler reports it, without the latency of separate event markers
 hipError_t launch_one(const vrt::KArgs &a, const vrt::ViewSet &vs, int grid, size_t lds_bytes, hipStream_t s,
@@ -121,17 +142,17 @@ hipError_t launch_one(const vrt::KArgs &a, const vrt::ViewSet &vs, int grid, siz
     if (lds_bytes > 48 * 1024) {  // above the default dynamic-LDS ceiling: opt in (CDNA4 has 160 KiB per CU)
         static bool raised = false;
         if (!raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST, SCHED>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             if (e != hipSuccess) return e;
             raised = true;
         }
     }
     if (ev0)
-        hipExtLaunchKernelGGL((vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST>), dim3(grid, a.n_views), dim3(BLOCK), lds_bytes, s,
+        hipExtLaunchKernelGGL((vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST, SCHED>), dim3(grid, a.n_views), dim3(BLOCK), lds_bytes, s,
                               ev0, ev1, 0, a, vs);
     else
-        hipLaunchKernelGGL((vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST>), dim3(grid, a.n_views), dim3(BLOCK), lds_bytes, s, a, vs);
+        hipLaunchKernelGGL((vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST, SCHED>), dim3(grid, a.n_views), dim3(BLOCK), lds_bytes, s, a, vs);
     return hipGetLastError();
 }
 
@@ -164,13 +185,62 @@ hipError_t launch_mode(const Variant &v, const vrt::KArgs &a, const vrt::ViewSet
         case 2100000 + 8000 + 40 + 1: return launch_one<MODE, V2L, 8, 256, 1>(a, vs, grid, lds, s, ev0, ev1);
         case 2100000 + 8000 + 160 + 1: return launch_one<MODE, V2L, 8, 1024, 1>(a, vs, grid, lds, s, ev0, ev1);
         case 3000000 + 8000 + 40 + 1: return launch_one<MODE, V3, 8, 256, 1>(a, vs, grid, lds, s, ev0, ev1);
-        case 3000000 + 8000 + 40 + 6: return launch_one<MODE, V3, 8, 256, 6>(a, vs, grid, lds, s, ev0, ev1);
+        case 3000000 + 8000 + 40 + 6:  // the default; the only combination with the feedback-scheduled flavours
+            switch ((a.wg_order ? 1 : 0) | (a.tile_cost ? 2 : 0)) {
+                case 1: return launch_one<MODE, V3, 8, 256, 6, false, 1>(a, vs, grid, lds, s, ev0, ev1);
+                case 2: return launch_one<MODE, V3, 8, 256, 6, false, 2>(a, vs, grid, lds, s, ev0, ev1);
+                case 3: return launch_one<MODE, V3, 8, 256, 6, false, 3>(a, vs, grid, lds, s, ev0, ev1);
+                default: return launch_one<MODE, V3, 8, 256, 6>(a, vs, grid, lds, s, ev0, ev1);
+            }
         case 3000000 + 8000 + 40 + 8: return launch_one<MODE, V3, 8, 256, 8>(a, vs, grid, lds, s, ev0, ev1);
         case 3000000 + 8000 + 10 + 1: return launch_one<MODE, V3, 8, 64, 1>(a, vs, grid, lds, s, ev0, ev1);
         case 3000000 + 8000 + 10 + 8: return launch_one<MODE, V3, 8, 64, 8>(a, vs, grid, lds, s, ev0, ev1);
         case 3000000 + 16000 + 40 + 1: return launch_one<MODE, V3, 16, 256, 1>(a, vs, grid, lds, s, ev0, ev1);
         default: return hipErrorInvalidValue;
     }
+}
+
+constexpr long kSchedMinGroups = 2048;   // below ~2 workgroups per CU there is no tail to shape
+constexpr long kSchedMaxGroups = 36864;  // tile_order_kernel keeps one word per workgroup in LDS (144 KiB of 160)
+constexpr size_t kSchedMaxStates = 8;
+
+// The scheduling state for this launch shape on this stream (created on first use; the least recently used one is
+// recycled when there are kSchedMaxStates). nullptr when device memory for it cannot be had: the launch then runs plain.
+SchedState *sched_state(vrt_ctx *c, hipStream_t s, int width, int n_rows, int row0, int row_stride, int tile_rows, int mode,
+                        uint32_t n_tiles, uint32_t n_wg) {
+    static uint64_t tick = 0;
+    ++tick;
+    for (SchedState &st : c->sched)
+        if (st.stream == s && st.width == width && st.n_rows == n_rows && st.row0 == row0 && st.row_stride == row_stride &&
+            st.tile_rows == tile_rows && st.mode == mode && st.n_tiles == n_tiles && st.n_wg == n_wg) {
+            st.last_use = tick;
+            return &st;
+        }
+    SchedState *slot = nullptr;
+    if (c->sched.size() < kSchedMaxStates) {
+        c->sched.emplace_back();
+        slot = &c->sched.back();
+    } else {
+        for (SchedState &st : c->sched)
+            if (!slot || st.last_use < slot->last_use) slot = &st;
+        // the recycled buffers may still be read by launches in flight on the old stream
+        if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+        (void)hipFree(slot->d_cost);
+        (void)hipFree(slot->d_order);
+        *slot = SchedState{};
+    }
+    if (hipMalloc((void **)&slot->d_cost, (size_t)n_tiles * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&slot->d_order, (size_t)n_wg * sizeof(uint32_t)) != hipSuccess) {
+        (void)hipFree(slot->d_cost);
+        (void)hipFree(slot->d_order);
+        *slot = SchedState{};
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    slot->stream = s; slot->width = width; slot->n_rows = n_rows; slot->row0 = row0; slot->row_stride = row_stride;
+    slot->tile_rows = tile_rows; slot->mode = mode; slot->n_tiles = n_tiles; slot->n_wg = n_wg;
+    slot->last_use = tick;
+    return slot;
 }
 
 // Builds the kernel arguments for local rows [0, n_rows) and enqueues one launch.
@@ -251,6 +321,8 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     a.root_table = c->d_roots;
     a.root0_node = a.n_roots ? c->wide.roots[0].node : 0u;
     a.root0_shift = a.n_roots ? c->wide.roots[0].shift : 0;
+    a.wg_order = nullptr;
+    a.tile_cost = nullptr;
 
     const int th = 64 / v.tw;
     const long tiles = (long)((width + v.tw - 1) / v.tw) * (long)((n_rows + th - 1) / th);
@@ -262,6 +334,22 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     }
     if (grid < 1) grid = 1;
     const size_t lds_bytes = (size_t)a.lds_records * sizeof(uint2);
+    // feedback scheduling: default kernel, one view, launches large enough to have a tail worth shaping
+    SchedState *st = nullptr;
+    bool measure = false;
+    const bool sched_kernel = v.trav == 3 && !v.use_lds && v.tw == 8 && v.block == 256 && v.wpe == 6 && v.blocks_per_cu == 0 &&
+                              mode != VRT_MODE_FULL && n_views == 1;
+    if (sched_kernel && c->dbg_sched) {
+        a.wg_order = c->dbg_wg_order;
+        a.tile_cost = c->dbg_tile_cost;
+    } else if (sched_kernel && c->sched_period > 0 && grid >= kSchedMinGroups && grid <= kSchedMaxGroups) {
+        st = sched_state(c, s, width, n_rows, row0, row_stride, tile_rows, mode, (uint32_t)tiles, (uint32_t)grid);
+        if (st) {
+            measure = st->launches % (uint64_t)c->sched_period == 0;
+            a.wg_order = st->valid ? st->d_order : nullptr;
+            a.tile_cost = measure ? st->d_cost : nullptr;
+        }
+    }
     const bool prof = c->profiling && (c->prof_seen++ % c->prof_stride) == 0 && (c->prof_count + 1) * 2 <= c->prof_events.size();
     const hipEvent_t ev0 = prof ? c->prof_events[2 * c->prof_count] : nullptr;
     const hipEvent_t ev1 = prof ? c->prof_events[2 * c->prof_count + 1] : nullptr;
@@ -277,6 +365,22 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
                                        : launch_mode<1>(v, a, vs, (int)grid, lds_bytes, s, ev0, ev1);
     }
     if (e != hipSuccess) return fail(c, VRT_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    if (st) {
+        ++st->launches;
+        if (measure) {  // same stream: reads this launch's ticks, rewrites the order the next launches read
+            static bool raised = false;
+            const size_t lds = (size_t)st->n_wg * sizeof(uint32_t);
+            if (lds > 48 * 1024 && !raised) {
+                VRT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&vrt::tile_order_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kSchedMaxGroups * sizeof(uint32_t))));
+                raised = true;
+            }
+            hipLaunchKernelGGL(vrt::tile_order_kernel, dim3(1), dim3(1024), lds, s, st->d_cost, st->n_tiles, (uint32_t)waves,
+                               st->n_wg, st->d_order);
+            VRT_HIP(c, hipGetLastError());
+            st->valid = true;
+        }
+    }
     if (prof) ++c->prof_count;
     c->info.lds_records = a.lds_records;
     return VRT_OK;
@@ -350,6 +454,11 @@ void vrt_destroy(vrt_ctx *c) {
     if (c->d_rgba) (void)hipFree(c->d_rgba);
     if (c->d_id) (void)hipFree(c->d_id);
     if (c->d_shown) (void)hipFree(c->d_shown);
+    if (!c->sched.empty()) (void)hipDeviceSynchronize();  // their launches may be on the caller's streams
+    for (SchedState &st : c->sched) {
+        (void)hipFree(st.d_cost);
+        (void)hipFree(st.d_order);
+    }
     for (auto &e : c->prof_events) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -640,6 +749,13 @@ int vrt_set_camera(vrt_ctx *c, const float inv_projection[16], const float inv_v
     return VRT_OK;
 }
 
+int vrt_set_tile_scheduling(vrt_ctx *c, int period) {
+    if (!c) return VRT_E_INVALID;
+    if (period < 0) return fail(c, VRT_E_INVALID, "vrt_set_tile_scheduling: period must be >= 0");
+    c->sched_period = period;
+    return VRT_OK;
+}
+
 int vrt_set_variant(vrt_ctx *c, int variant) {
     if (!c) return VRT_E_INVALID;
     if (variant < 0 || variant >= kNumVariants) return fail(c, VRT_E_INVALID, "vrt_set_variant: unknown variant");
@@ -860,6 +976,32 @@ int vrt_debug_set_denoise_variant(vrt_ctx *c, int v) {
     if (!c || v < 0 || v > 1) return VRT_E_INVALID;
     c->denoise_variant = v;
     return VRT_OK;
+}
+
+// Experiment hook (tools/tile_order_ab.py): caller-owned device buffers -- a workgroup permutation and/or a per-tile
+// tick buffer -- for the default kernel instead of the scheduler's own (KArgs::wg_order / tile_cost). enable = 0
+// hands the launches back to the scheduler.
+int vrt_debug_set_tile_order(vrt_ctx *c, int enable, const void *d_wg_order, void *d_tile_cost) {
+    if (!c) return VRT_E_INVALID;
+    c->dbg_sched = enable != 0;
+    c->dbg_wg_order = enable ? (const uint32_t *)d_wg_order : nullptr;
+    c->dbg_tile_cost = enable ? (uint32_t *)d_tile_cost : nullptr;
+    return VRT_OK;
+}
+
+// Reads back the scheduler's current workgroup order for the shape last launched on `stream` (tests): returns the
+// number of workgroups (0 when no order has been derived yet), at most `cap` entries copied.
+long vrt_debug_sched_order(vrt_ctx *c, void *stream, uint32_t *out, size_t cap) {
+    if (!c) return VRT_E_INVALID;
+    const SchedState *best = nullptr;
+    for (const SchedState &st : c->sched)
+        if (st.stream == (stream ? (hipStream_t)stream : c->stream) && (!best || st.last_use > best->last_use)) best = &st;
+    if (!best || !best->valid) return 0;
+    VRT_HIP(c, hipSetDevice(c->device));
+    VRT_HIP(c, hipStreamSynchronize(best->stream));
+    const size_t n = best->n_wg < cap ? best->n_wg : cap;
+    if (out && n) VRT_HIP(c, hipMemcpy(out, best->d_order, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return (long)best->n_wg;
 }
 
 int vrt_debug_math(vrt_ctx *c, int op, const float *x, const float *y, float *out, int n) {

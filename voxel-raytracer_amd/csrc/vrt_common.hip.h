@@ -71,6 +71,11 @@ struct KArgs {
     uint32_t root0_node;
     int root0_shift;
     int root0_min[3];         // minimum corner of wide root 0's cube (valid when n_roots > 0)
+    // Feedback scheduling (SCHED flavours of trace_kernel; vrt_capi.hip owns the buffers). bit 0: workgroup b traces
+    // tile group wg_order[b] (a permutation of the launch's workgroups, heaviest first). bit 1: every wave leaves the
+    // clock ticks its tile took in tile_cost[tile], from which tile_order_kernel derives the next order.
+    const uint32_t *wg_order;
+    uint32_t *tile_cost;
 };
 
 #define VRT_DEV __device__ __forceinline__
@@ -278,7 +283,7 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
 // One lane per pixel; a wave covers a TW x TH pixel tile (TW*TH == 64) so the 64 rays of a wave
 // stay spatially coherent; workgroups walk tiles with a grid-stride loop.
 // WPE: waves per SIMD the register allocator must leave room for (1 = no constraint beyond BLOCK).
-template <int MODE, class TRAV, int TW, int BLOCK, int WPE = 1, bool PERSIST = false>
+template <int MODE, class TRAV, int TW, int BLOCK, int WPE = 1, bool PERSIST = false, int SCHED = 0>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) void trace_kernel(const KArgs a, const ViewSet vs) {
     extern __shared__ __attribute__((aligned(16))) uint2 lds_dyn[];
     constexpr int TH = 64 / TW;
@@ -297,7 +302,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
     // PERSIST: a fixed grid walks the tiles with a grid-stride loop. Otherwise one tile per wave and no loop:
     // without the back edge the kernel arguments need not stay live after ray generation, which is worth
     // ~19 VGPRs (88 -> 69) and two thirds of the SGPR spills on gfx950.
-    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
+    static_assert(!(PERSIST && SCHED), "the scheduled flavours trace one tile per wave");
+    int group = blockIdx.x;
+    if constexpr (SCHED & 1) group = (int)a.wg_order[blockIdx.x];
+    unsigned long long t_begin = 0;
+    if constexpr (SCHED & 2) t_begin = __builtin_readcyclecounter();
+    for (int tile = group * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
         int tx = tile % tiles_x, ty = tile / tiles_x;
         int px = tx * TW + lx;
         int j = ty * TH + ly;
@@ -312,8 +322,48 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
             if (vw.out_rgba) vw.out_rgba[o] = rgba;
             if (vw.out_id) vw.out_id[o] = idd;
         }
+        if constexpr (SCHED & 2) {  // the wave has reconverged: this is the time its slowest ray took
+            if (lane == 0) a.tile_cost[tile] = (uint32_t)(__builtin_readcyclecounter() - t_begin);
+        }
         if constexpr (!PERSIST) break;
     }
+}
+
+// Feedback scheduling, second half: turns the per-tile ticks of one frame into the workgroup order of the next ones.
+// The hardware starts workgroups in index order, and a launch ends when its last-started, slowest workgroups drain; started
+// heaviest first, the tail consists of the cheapest tiles instead (longest-processing-time-first list scheduling). A
+// workgroup's cost is the maximum over its `waves` tiles; workgroups are bucketed by cost (256 linear buckets up to
+// the frame's maximum) and written out from the heaviest bucket down. One workgroup of 1024 lanes; any permutation is
+// correct for the trace kernel, the costs only decide how good it is.
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *tile_cost, uint32_t n_tiles, uint32_t waves,
+                                                          uint32_t n_wg, uint32_t *wg_order) {
+    extern __shared__ uint32_t wg_cost[];  // n_wg
+    __shared__ uint32_t hist[256], top;
+    const uint32_t t = threadIdx.x;
+    if (t < 256) hist[t] = 0;
+    if (t == 0) top = 0;
+    __syncthreads();
+    uint32_t m = 0;
+    for (uint32_t g = t; g < n_wg; g += 1024) {
+        uint32_t c = 0;
+        for (uint32_t k = 0; k < waves; ++k) {
+            const uint32_t tile = g * waves + k;
+            if (tile < n_tiles) { const uint32_t v = tile_cost[tile]; c = v > c ? v : c; }
+        }
+        wg_cost[g] = c;
+        m = c > m ? c : m;
+    }
+    atomicMax(&top, m);
+    __syncthreads();
+    const uint32_t shift = top >= 256 ? 24 - (uint32_t)__builtin_clz(top) : 0;  // top >> shift <= 255
+    for (uint32_t g = t; g < n_wg; g += 1024) atomicAdd(&hist[wg_cost[g] >> shift], 1u);
+    __syncthreads();
+    if (t == 0) {  // hist[b] := first output slot of bucket b, heaviest bucket first
+        uint32_t acc = 0;
+        for (int b = 255; b >= 0; --b) { const uint32_t n = hist[b]; hist[b] = acc; acc += n; }
+    }
+    __syncthreads();
+    for (uint32_t g = t; g < n_wg; g += 1024) wg_order[atomicAdd(&hist[wg_cost[g] >> shift], 1u)] = g;
 }
 
 // exactness probe for the arithmetic contract: out[i] = op(x[i], y[i])
