@@ -10,7 +10,7 @@ from conftest import MAPS
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = list(range(19))
+VARIANTS = list(range(20))
 
 
 @pytest.fixture(scope="module")
@@ -90,6 +90,8 @@ def test_full_mode_math_conventions_match_oracle(ctx, O):
     f = np.concatenate([rng.uniform(-1100, 1100, 50000), [-0.0, 0.0, -1e-40, 1e-40, -1.0, 1.0, -0.99999994, 1023.9999],
                         np.arange(-8, 8) + 1e-4, np.arange(-8, 8) - 1e-4]).astype(np.float32)
     assert np.array_equal(ctx.debug_math(13, f, f), np.floor(f).astype(np.int32).astype(np.float32))
+    byte = np.arange(256, dtype=np.float32)   # colour/property bytes -> [0, 1] without a division (vrt_common.hip.h unorm_of)
+    assert np.array_equal(ctx.debug_math(15, byte, byte).view(np.uint32), (byte / np.float32(255.0)).view(np.uint32))
     u = rng.integers(0, 2 ** 32, 50000, dtype=np.uint64).astype(np.uint32)
     u[:4] = [0, 0xffffffff, 0xffffff7f, 0x80000000]
     ref_u = (u.astype(np.float32) / np.float32(4294967296.0)).astype(np.float32)

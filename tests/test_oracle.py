@@ -129,3 +129,27 @@ def test_denoise_restatement_properties(O):
     # mean of the 3x3 window around the outlier: (255 + 8*90)/9 etc.
     c = out2[20, 45, :3]
     assert abs(int(c[0]) - round((255 + 8 * 90) / 9)) <= 1 and abs(int(c[1]) - round(8 * 90 / 9)) <= 1
+
+
+def test_byte_to_unorm_without_division_is_exact():
+    """The kernels turn a byte b into (float)b / 255.0f as q = b * RN(1/255); q + fma(-q, 255, b) * RN(1/255), both steps
+    fused (vrt_common.hip.h unorm_of). Exact rational arithmetic: that equals the correctly rounded quotient -- what the
+    shader's division (comp:173-177) and the oracle compute -- for every byte, while the bare product does not."""
+    from fractions import Fraction
+
+    def rn(x):  # nearest float32 to the rational x, ties to even
+        c = np.float32(float(x))
+        cands = [np.nextafter(c, np.float32(-np.inf)), c, np.nextafter(c, np.float32(np.inf))]
+        return min(cands, key=lambda v: (abs(Fraction(float(v)) - x), int(np.array(v).view(np.uint32)) & 1))
+
+    rcp = rn(Fraction(1, 255))
+    assert int(np.array(rcp).view(np.uint32)) == 0x3b808081
+    bare_wrong = 0
+    for b in range(256):
+        want = np.float32(b) / np.float32(255.0)
+        assert rn(Fraction(b, 255)) == want
+        q = rn(Fraction(b) * Fraction(float(rcp)))
+        bare_wrong += q != want
+        e = rn(Fraction(b) - Fraction(float(q)) * 255)
+        assert rn(Fraction(float(e)) * Fraction(float(rcp)) + Fraction(float(q))) == want, b
+    assert bare_wrong > 100

@@ -35,7 +35,7 @@ struct Variant {
 // variant 0 is the default the library ships with; the others exist for A/B measurement
 // (see launch_mode() for the combinations that are instantiated)
 const Variant kVariants[] = {
-    /*0*/ {3, false, 8, 256, 0, 0, 6},
+    /*0*/ {3, false, 8, 64, 0, 0, 6},
     /*1*/ {1, false, 8, 256, 0, 0, 1},
     /*2*/ {2, true, 8, 256, 2048, 0, 1},
     /*3*/ {2, false, 16, 256, 0, 0, 1},
@@ -54,6 +54,7 @@ const Variant kVariants[] = {
     /*16*/ {3, false, 8, 64, 0, 0, 1},
     /*17*/ {3, false, 8, 64, 0, 0, 8},
     /*18*/ {3, false, 16, 256, 0, 0, 1},
+    /*19*/ {3, false, 8, 64, 0, 0, 7},
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -67,7 +68,7 @@ constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 struct SchedState {
     hipStream_t stream = nullptr;
     int width = 0, n_rows = 0, row0 = 0, row_stride = 0, tile_rows = 0, mode = 0;
-    uint32_t n_tiles = 0, n_wg = 0;
+    uint32_t n_tiles = 0, n_groups = 0;
     uint32_t *d_cost = nullptr, *d_order = nullptr;
     bool valid = false;        // d_order holds an order
     uint64_t launches = 0;
@@ -114,7 +115,7 @@ struct vrt_ctx {
     // feedback scheduling of the default kernel (see SchedState)
     int sched_period = 16;                   // every n-th launch of a shape measures its tiles; 0 = off
     std::vector<SchedState> sched;
-    const uint32_t *dbg_wg_order = nullptr;  // vrt_debug_set_tile_order: caller-owned buffers instead of the scheduler's
+    const uint32_t *dbg_group_order = nullptr;  // vrt_debug_set_tile_order: caller-owned buffers instead of the scheduler's
     uint32_t *dbg_tile_cost = nullptr;
     bool dbg_sched = false;
     std::string err;
@@ -139,21 +140,31 @@ template <int MODE, class TRAV, int TW, int BLOCK, int WPE, bool PERSIST = false
 // the kernel's own begin-to-end time, as a profiler reports it, without the latency of separate event markers
 hipError_t launch_one(const vrt::KArgs &a, const vrt::ViewSet &vs, int grid, size_t lds_bytes, hipStream_t s,
                       hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {  // grid.y = a.n_views
+    void (*kernel)(const vrt::KArgs, const vrt::ViewSet) = &vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST, SCHED>;
     if (lds_bytes > 48 * 1024) {  // above the default dynamic-LDS ceiling: opt in (CDNA4 has 160 KiB per CU)
         static bool raised = false;
         if (!raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST, SCHED>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             if (e != hipSuccess) return e;
             raised = true;
         }
     }
     if (ev0)
-        hipExtLaunchKernelGGL((vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST, SCHED>), dim3(grid, a.n_views), dim3(BLOCK), lds_bytes, s,
-                              ev0, ev1, 0, a, vs);
+        hipExtLaunchKernelGGL(kernel, dim3(grid, a.n_views), dim3(BLOCK), lds_bytes, s, ev0, ev1, 0, a, vs);
     else
-        hipLaunchKernelGGL((vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST, SCHED>), dim3(grid, a.n_views), dim3(BLOCK), lds_bytes, s, a, vs);
+        hipLaunchKernelGGL(kernel, dim3(grid, a.n_views), dim3(BLOCK), lds_bytes, s, a, vs);
     return hipGetLastError();
+}
+
+// The combinations that exist in the feedback-scheduled flavours too (KArgs::group_order / tile_cost choose one).
+template <int MODE, class TRAV, int TW, int BLOCK, int WPE>
+hipError_t launch_sched(const vrt::KArgs &a, const vrt::ViewSet &vs, int grid, size_t lds, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    switch ((a.group_order ? 1 : 0) | (a.tile_cost ? 2 : 0)) {
+        case 1: return launch_one<MODE, TRAV, TW, BLOCK, WPE, false, 1>(a, vs, grid, lds, s, ev0, ev1);
+        case 2: return launch_one<MODE, TRAV, TW, BLOCK, WPE, false, 2>(a, vs, grid, lds, s, ev0, ev1);
+        case 3: return launch_one<MODE, TRAV, TW, BLOCK, WPE, false, 3>(a, vs, grid, lds, s, ev0, ev1);
+        default: return launch_one<MODE, TRAV, TW, BLOCK, WPE>(a, vs, grid, lds, s, ev0, ev1);
+    }
 }
 
 // The instantiated (traversal, LDS prefix, tile width, workgroup size, waves-per-SIMD) combinations.
@@ -185,14 +196,10 @@ hipError_t launch_mode(const Variant &v, const vrt::KArgs &a, const vrt::ViewSet
         case 2100000 + 8000 + 40 + 1: return launch_one<MODE, V2L, 8, 256, 1>(a, vs, grid, lds, s, ev0, ev1);
         case 2100000 + 8000 + 160 + 1: return launch_one<MODE, V2L, 8, 1024, 1>(a, vs, grid, lds, s, ev0, ev1);
         case 3000000 + 8000 + 40 + 1: return launch_one<MODE, V3, 8, 256, 1>(a, vs, grid, lds, s, ev0, ev1);
-        case 3000000 + 8000 + 40 + 6:  // the default; the only combination with the feedback-scheduled flavours
-            switch ((a.wg_order ? 1 : 0) | (a.tile_cost ? 2 : 0)) {
-                case 1: return launch_one<MODE, V3, 8, 256, 6, false, 1>(a, vs, grid, lds, s, ev0, ev1);
-                case 2: return launch_one<MODE, V3, 8, 256, 6, false, 2>(a, vs, grid, lds, s, ev0, ev1);
-                case 3: return launch_one<MODE, V3, 8, 256, 6, false, 3>(a, vs, grid, lds, s, ev0, ev1);
-                default: return launch_one<MODE, V3, 8, 256, 6>(a, vs, grid, lds, s, ev0, ev1);
-            }
+        case 3000000 + 8000 + 40 + 6: return launch_sched<MODE, V3, 8, 256, 6>(a, vs, grid, lds, s, ev0, ev1);
         case 3000000 + 8000 + 40 + 8: return launch_one<MODE, V3, 8, 256, 8>(a, vs, grid, lds, s, ev0, ev1);
+        case 3000000 + 8000 + 10 + 6: return launch_sched<MODE, V3, 8, 64, 6>(a, vs, grid, lds, s, ev0, ev1);
+        case 3000000 + 8000 + 10 + 7: return launch_sched<MODE, V3, 8, 64, 7>(a, vs, grid, lds, s, ev0, ev1);
         case 3000000 + 8000 + 10 + 1: return launch_one<MODE, V3, 8, 64, 1>(a, vs, grid, lds, s, ev0, ev1);
         case 3000000 + 8000 + 10 + 8: return launch_one<MODE, V3, 8, 64, 8>(a, vs, grid, lds, s, ev0, ev1);
         case 3000000 + 16000 + 40 + 1: return launch_one<MODE, V3, 16, 256, 1>(a, vs, grid, lds, s, ev0, ev1);
@@ -200,19 +207,19 @@ hipError_t launch_mode(const Variant &v, const vrt::KArgs &a, const vrt::ViewSet
     }
 }
 
-constexpr long kSchedMinGroups = 2048;   // below ~2 workgroups per CU there is no tail to shape
-constexpr long kSchedMaxGroups = 36864;  // tile_order_kernel keeps one word per workgroup in LDS (144 KiB of 160)
+constexpr long kSchedMinGroups = 2048;   // below ~8 tiles per SIMD there is no tail to shape
+constexpr long kSchedMaxGroups = 36864;  // tile_order_kernel keeps one word per group in LDS (144 KiB of 160)
 constexpr size_t kSchedMaxStates = 8;
 
 // The scheduling state for this launch shape on this stream (created on first use; the least recently used one is
 // recycled when there are kSchedMaxStates). nullptr when device memory for it cannot be had: the launch then runs plain.
 SchedState *sched_state(vrt_ctx *c, hipStream_t s, int width, int n_rows, int row0, int row_stride, int tile_rows, int mode,
-                        uint32_t n_tiles, uint32_t n_wg) {
+                        uint32_t n_tiles, uint32_t n_groups) {
     static uint64_t tick = 0;
     ++tick;
     for (SchedState &st : c->sched)
         if (st.stream == s && st.width == width && st.n_rows == n_rows && st.row0 == row0 && st.row_stride == row_stride &&
-            st.tile_rows == tile_rows && st.mode == mode && st.n_tiles == n_tiles && st.n_wg == n_wg) {
+            st.tile_rows == tile_rows && st.mode == mode && st.n_tiles == n_tiles && st.n_groups == n_groups) {
             st.last_use = tick;
             return &st;
         }
@@ -230,7 +237,7 @@ SchedState *sched_state(vrt_ctx *c, hipStream_t s, int width, int n_rows, int ro
         *slot = SchedState{};
     }
     if (hipMalloc((void **)&slot->d_cost, (size_t)n_tiles * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void **)&slot->d_order, (size_t)n_wg * sizeof(uint32_t)) != hipSuccess) {
+        hipMalloc((void **)&slot->d_order, (size_t)n_groups * sizeof(uint32_t)) != hipSuccess) {
         (void)hipFree(slot->d_cost);
         (void)hipFree(slot->d_order);
         *slot = SchedState{};
@@ -238,7 +245,7 @@ SchedState *sched_state(vrt_ctx *c, hipStream_t s, int width, int n_rows, int ro
         return nullptr;
     }
     slot->stream = s; slot->width = width; slot->n_rows = n_rows; slot->row0 = row0; slot->row_stride = row_stride;
-    slot->tile_rows = tile_rows; slot->mode = mode; slot->n_tiles = n_tiles; slot->n_wg = n_wg;
+    slot->tile_rows = tile_rows; slot->mode = mode; slot->n_tiles = n_tiles; slot->n_groups = n_groups;
     slot->last_use = tick;
     return slot;
 }
@@ -267,8 +274,15 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
         v.trav = 1; v.tw = 8; v.block = 256; v.wpe = 1;
         if (v.lds_cap > 2048) v.lds_cap = 2048;
     }
-    if (mode == VRT_MODE_FULL) {  // one launch shape per traversal for the full path tracer
-        v.use_lds = false; v.tw = 8; v.block = 256; v.wpe = 1; v.lds_cap = 0;
+    if (mode == VRT_MODE_FULL) {
+        // the full path tracer exists for the wide traversal (64- or 256-lane workgroups, five waves per SIMD: 96 VGPRs
+        // and no extra spills measured 8-10 % faster than the unconstrained 105-VGPR build) and, as baselines, for
+        // the other two in one shape each
+        v.use_lds = false; v.tw = 8; v.lds_cap = 0; v.blocks_per_cu = 0;
+        if (v.trav == 3) { v.block = v.block == 64 ? 64 : 256; v.wpe = 5; }
+        else { v.block = 256; v.wpe = 1; }
+    } else if (mode == VRT_MODE_PRIMARY_SHADOW && c->variant == 0 && v.trav == 3) {
+        v.wpe = 7;  // the default kernel with the shadow march is 1.5 % faster seven waves deep, the primary one six deep
     }
     vrt::KArgs a;
     vrt::ViewSet vs;
@@ -321,7 +335,7 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     a.root_table = c->d_roots;
     a.root0_node = a.n_roots ? c->wide.roots[0].node : 0u;
     a.root0_shift = a.n_roots ? c->wide.roots[0].shift : 0;
-    a.wg_order = nullptr;
+    a.group_order = nullptr;
     a.tile_cost = nullptr;
 
     const int th = 64 / v.tw;
@@ -334,30 +348,32 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     }
     if (grid < 1) grid = 1;
     const size_t lds_bytes = (size_t)a.lds_records * sizeof(uint2);
-    // feedback scheduling: default kernel, one view, launches large enough to have a tail worth shaping
+    // feedback scheduling: wide-traversal kernels, one view, launches large enough to have a tail worth shaping
     SchedState *st = nullptr;
     bool measure = false;
-    const bool sched_kernel = v.trav == 3 && !v.use_lds && v.tw == 8 && v.block == 256 && v.wpe == 6 && v.blocks_per_cu == 0 &&
-                              mode != VRT_MODE_FULL && n_views == 1;
+    const bool sched_kernel = v.trav == 3 && !v.use_lds && v.tw == 8 && v.blocks_per_cu == 0 && n_views == 1 &&
+                              ((v.block == 64 && (v.wpe == 5 || v.wpe == 6 || v.wpe == 7)) ||
+                               (v.block == 256 && (v.wpe == 5 || v.wpe == 6)));
+    const long groups = (tiles + vrt::kGroupTiles - 1) / vrt::kGroupTiles;
     if (sched_kernel && c->dbg_sched) {
-        a.wg_order = c->dbg_wg_order;
+        a.group_order = c->dbg_group_order;
         a.tile_cost = c->dbg_tile_cost;
-    } else if (sched_kernel && c->sched_period > 0 && grid >= kSchedMinGroups && grid <= kSchedMaxGroups) {
-        st = sched_state(c, s, width, n_rows, row0, row_stride, tile_rows, mode, (uint32_t)tiles, (uint32_t)grid);
+    } else if (sched_kernel && c->sched_period > 0 && groups >= kSchedMinGroups && groups <= kSchedMaxGroups) {
+        st = sched_state(c, s, width, n_rows, row0, row_stride, tile_rows, mode, (uint32_t)tiles, (uint32_t)groups);
         if (st) {
             measure = st->launches % (uint64_t)c->sched_period == 0;
-            a.wg_order = st->valid ? st->d_order : nullptr;
+            a.group_order = st->valid ? st->d_order : nullptr;
             a.tile_cost = measure ? st->d_cost : nullptr;
         }
     }
+    if (a.group_order) grid = groups * (vrt::kGroupTiles / waves);  // whole groups: the last one may hold tiles past the end
     const bool prof = c->profiling && (c->prof_seen++ % c->prof_stride) == 0 && (c->prof_count + 1) * 2 <= c->prof_events.size();
     const hipEvent_t ev0 = prof ? c->prof_events[2 * c->prof_count] : nullptr;
     const hipEvent_t ev1 = prof ? c->prof_events[2 * c->prof_count + 1] : nullptr;
     hipError_t e;
     if (mode == VRT_MODE_FULL) {
-        // the full path tracer is instantiated for the default traversal and for the explicit-AABB baseline only; five
-        // waves per SIMD (96 VGPRs, no extra spills) measured 8-10 % faster than the unconstrained 105-VGPR build
-        if (v.trav == 3) e = launch_one<2, vrt::v3::Trav, 8, 256, 5>(a, vs, (int)grid, 0, s, ev0, ev1);
+        if (v.trav == 3 && v.block == 64) e = launch_sched<2, vrt::v3::Trav, 8, 64, 5>(a, vs, (int)grid, 0, s, ev0, ev1);
+        else if (v.trav == 3) e = launch_sched<2, vrt::v3::Trav, 8, 256, 5>(a, vs, (int)grid, 0, s, ev0, ev1);
         else if (v.trav == 2) e = launch_one<2, vrt::v2::Trav<false>, 8, 256, 1>(a, vs, (int)grid, 0, s);
         else e = launch_one<2, vrt::v1::Trav<false>, 8, 256, 1>(a, vs, (int)grid, 0, s);
     } else {
@@ -369,14 +385,14 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
         ++st->launches;
         if (measure) {  // same stream: reads this launch's ticks, rewrites the order the next launches read
             static bool raised = false;
-            const size_t lds = (size_t)st->n_wg * sizeof(uint32_t);
+            const size_t lds = (size_t)st->n_groups * sizeof(uint32_t);
             if (lds > 48 * 1024 && !raised) {
                 VRT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&vrt::tile_order_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kSchedMaxGroups * sizeof(uint32_t))));
                 raised = true;
             }
-            hipLaunchKernelGGL(vrt::tile_order_kernel, dim3(1), dim3(1024), lds, s, st->d_cost, st->n_tiles, (uint32_t)waves,
-                               st->n_wg, st->d_order);
+            hipLaunchKernelGGL(vrt::tile_order_kernel, dim3(1), dim3(1024), lds, s, st->d_cost, st->n_tiles, st->n_groups,
+                               st->d_order);
             VRT_HIP(c, hipGetLastError());
             st->valid = true;
         }
@@ -979,12 +995,12 @@ int vrt_debug_set_denoise_variant(vrt_ctx *c, int v) {
 }
 
 // Experiment hook (tools/tile_order_ab.py): caller-owned device buffers -- a workgroup permutation and/or a per-tile
-// tick buffer -- for the default kernel instead of the scheduler's own (KArgs::wg_order / tile_cost). enable = 0
+// tick buffer -- for the default kernel instead of the scheduler's own (KArgs::group_order / tile_cost). enable = 0
 // hands the launches back to the scheduler.
-int vrt_debug_set_tile_order(vrt_ctx *c, int enable, const void *d_wg_order, void *d_tile_cost) {
+int vrt_debug_set_tile_order(vrt_ctx *c, int enable, const void *d_group_order, void *d_tile_cost) {
     if (!c) return VRT_E_INVALID;
     c->dbg_sched = enable != 0;
-    c->dbg_wg_order = enable ? (const uint32_t *)d_wg_order : nullptr;
+    c->dbg_group_order = enable ? (const uint32_t *)d_group_order : nullptr;
     c->dbg_tile_cost = enable ? (uint32_t *)d_tile_cost : nullptr;
     return VRT_OK;
 }
@@ -999,9 +1015,9 @@ long vrt_debug_sched_order(vrt_ctx *c, void *stream, uint32_t *out, size_t cap) 
     if (!best || !best->valid) return 0;
     VRT_HIP(c, hipSetDevice(c->device));
     VRT_HIP(c, hipStreamSynchronize(best->stream));
-    const size_t n = best->n_wg < cap ? best->n_wg : cap;
+    const size_t n = best->n_groups < cap ? best->n_groups : cap;
     if (out && n) VRT_HIP(c, hipMemcpy(out, best->d_order, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    return (long)best->n_wg;
+    return (long)best->n_groups;
 }
 
 int vrt_debug_math(vrt_ctx *c, int op, const float *x, const float *y, float *out, int n) {

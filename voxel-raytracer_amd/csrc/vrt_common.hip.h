@@ -25,6 +25,7 @@ struct I3 { int x, y, z; };
 // views of a light-field rig -- share one launch, so the drain of one view's last waves is filled by the next
 // view's first instead of idling the chip between launches.
 constexpr int kMaxViews = 4;
+constexpr int kGroupTiles = 4;  // tiles per scheduling group: 4 adjacent 8x8 tiles, i.e. 32 x 8 pixels
 struct View {
     float inv_proj[16];
     float inv_view[16];
@@ -71,10 +72,11 @@ struct KArgs {
     uint32_t root0_node;
     int root0_shift;
     int root0_min[3];         // minimum corner of wide root 0's cube (valid when n_roots > 0)
-    // Feedback scheduling (SCHED flavours of trace_kernel; vrt_capi.hip owns the buffers). bit 0: workgroup b traces
-    // tile group wg_order[b] (a permutation of the launch's workgroups, heaviest first). bit 1: every wave leaves the
-    // clock ticks its tile took in tile_cost[tile], from which tile_order_kernel derives the next order.
-    const uint32_t *wg_order;
+    // Feedback scheduling (SCHED flavours of trace_kernel; vrt_capi.hip owns the buffers). The unit is a GROUP of
+    // kGroupTiles consecutive tiles. bit 0: the g-th group of tiles the launch starts is group_order[g] (a permutation
+    // of the launch's groups, heaviest first). bit 1: every wave leaves the clock ticks its tile took in
+    // tile_cost[tile], from which tile_order_kernel derives the next order.
+    const uint32_t *group_order;
     uint32_t *tile_cost;
 };
 
@@ -151,25 +153,33 @@ VRT_DEV void mat_vec(const float *m, float x, float y, float z, float w, float o
     for (int r = 0; r < 4; ++r) out[r] = (m[0 * 4 + r] * x + m[1 * 4 + r] * y) + (m[2 * 4 + r] * z + m[3 * 4 + r] * w);
 }
 
-// Leaf words -> the shader's VoxelData floats (comp:173-178). `unorm` is the workgroup's 256-entry
-// table of (float)b / 255.0f, built with that very division, so a lookup returns the same bits.
+// (float)b / 255.0f for a byte b, bit for bit, without the division: the product with the rounded reciprocal is off
+// by one ulp for 126 of the 256 bytes, and one residual step (both fused, as written) repairs all of them -- checked
+// exhaustively against the correctly rounded quotient (tests/test_oracle.py) and through every parity frame.
+VRT_DEV float unorm_of(float b) {
+    constexpr float kRcp255 = 0.003921568859368563f;  // 0x3b808081 = RN(1/255)
+    const float q = b * kRcp255;
+    return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, b), kRcp255, q);
+}
+
+// Leaf words -> the shader's VoxelData floats (comp:173-178).
 struct Decoded { float c[4]; float p[3]; };
-VRT_DEV Decoded decode_leaf(const float *unorm, uint32_t w0, uint32_t w1) {
+VRT_DEV Decoded decode_leaf(uint32_t w0, uint32_t w1) {
     Decoded d;
-    d.c[0] = unorm[w0 & 0xffu];
-    d.c[1] = unorm[(w0 >> 8) & 0xffu];
-    d.c[2] = unorm[(w0 >> 16) & 0xffu];
-    d.c[3] = unorm[w0 >> 24];
-    d.p[0] = unorm[w1 & 0xffu] * 3.0f;
-    d.p[1] = unorm[(w1 >> 8) & 0xffu];
-    d.p[2] = unorm[(w1 >> 16) & 0xffu];
+    d.c[0] = unorm_of((float)(w0 & 0xffu));
+    d.c[1] = unorm_of((float)((w0 >> 8) & 0xffu));
+    d.c[2] = unorm_of((float)((w0 >> 16) & 0xffu));
+    d.c[3] = unorm_of((float)(w0 >> 24));
+    d.p[0] = unorm_of((float)(w1 & 0xffu)) * 3.0f;
+    d.p[1] = unorm_of((float)((w1 >> 8) & 0xffu));
+    d.p[2] = unorm_of((float)((w1 >> 16) & 0xffu));
     return d;
 }
 
 // One pixel: ray generation (comp:624-641), primary-ray pathTrace, packing of the two outputs.
 // TRAV supplies the traversal: march(), shadow(). MODE: 0 primary, 1 primary + shadow ray.
 template <int MODE, class TRAV>
-VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, const float *unorm, int px, int py, uint32_t &rgba, int2 &idd) {
+VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, int px, int py, uint32_t &rgba, int2 &idd) {
     const float kPI = 3.14159265359f;
     float u = ((float)px / (float)a.width) * 2.0f - 1.0f;
     float v = ((float)py / (float)a.height) * 2.0f - 1.0f;
@@ -187,7 +197,7 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
     F3 gro = scale3(ray_origin, a.voxel_scale);
     // medium at the eye (comp:445-449)
     // medium at the eye (comp:445-449): the same node for every ray of the view, found once by the dispatcher
-    Decoded tvd = decode_leaf(unorm, vw.eye0, vw.eye1);
+    Decoded tvd = decode_leaf(vw.eye0, vw.eye1);
     float start_iof = (tvd.p[0] > 0.0f && tvd.p[0] < 3.0f) ? tvd.p[0] : 1.0f;
     float inv_len = 1.0f / __builtin_sqrtf(dot3(ray_dir, ray_dir));
     ray_dir = scale3(ray_dir, inv_len);
@@ -218,8 +228,8 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
         // distanceInMedium only feeds the absorption term, which needs mediumDensity > 0 (comp:501,512)
         float dist_in_medium = 0.0f;
         if (medium_density > 0.0f) dist_in_medium = 0.0f + len3(sub3(hpw, gro)) / a.voxel_scale;
-        Decoded hv = decode_leaf(unorm, h.h0, h.h1);
-        Decoded lv = decode_leaf(unorm, h.p0, h.p1);
+        Decoded hv = decode_leaf(h.h0, h.h1);
+        Decoded lv = decode_leaf(h.p0, h.p1);
         if (hv.c[3] <= 0.0f) { hv.p[0] = 1.0f; hv.p[1] = 0.0f; hv.p[2] = 0.0f; }
         if (lv.c[3] <= 0.0f) {
             if (start_iof > 0.0f) { lv.p[0] = 0.0f; lv.p[1] = 0.0f; lv.p[2] = 0.0f; }
@@ -277,8 +287,12 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
 
 namespace full {  // MODE 2, defined in vrt_full.hip.h
 template <class TRAV>
-__device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, const float *unorm, int px, int py, uint32_t &rgba, int2 &idd);
+__device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, int px, int py, uint32_t &rgba, int2 &idd);
 }
+
+// WPE also bounds the SCALAR registers: a SIMD admits floor(800 / (ceil(sgprs / 16) * 16 + 16)) waves
+// (MI355X_MICROARCH.md, "Residency") -- 6 with the 106 this kernel takes when unconstrained, whatever its 67 vector
+// registers would allow -- and amdgpu_waves_per_eu(7) makes the compiler stay within the 96 that admit 7.
 
 // One lane per pixel; a wave covers a TW x TH pixel tile (TW*TH == 64) so the 64 rays of a wave
 // stay spatially coherent; workgroups walk tiles with a grid-stride loop.
@@ -288,11 +302,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
     extern __shared__ __attribute__((aligned(16))) uint2 lds_dyn[];
     constexpr int TH = 64 / TW;
     constexpr int WAVES = BLOCK / 64;
-    __shared__ float unorm[256];  // (float)b / 255.0f for every byte b (comp:173-177), one correctly rounded division each
-    for (int i = threadIdx.x; i < 256; i += BLOCK) unorm[i] = (float)i / 255.0f;
     typename TRAV::Ctx tc_;
     TRAV::template block_init<BLOCK>(a, lds_dyn, tc_);
-    __syncthreads();
+    // only the traversals that stage records in LDS have anything to wait for: the others start tracing as soon
+    // as the wave is launched, without meeting the other waves of the workgroup
+    if constexpr (TRAV::kStagesLds) __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int tiles_x = (a.width + TW - 1) / TW;
@@ -303,11 +317,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
     // without the back edge the kernel arguments need not stay live after ray generation, which is worth
     // ~19 VGPRs (88 -> 69) and two thirds of the SGPR spills on gfx950.
     static_assert(!(PERSIST && SCHED), "the scheduled flavours trace one tile per wave");
-    int group = blockIdx.x;
-    if constexpr (SCHED & 1) group = (int)a.wg_order[blockIdx.x];
+    int first = blockIdx.x * WAVES;  // first tile of this workgroup
+    if constexpr (SCHED & 1) {
+        static_assert(kGroupTiles % WAVES == 0, "a scheduling group is a whole number of workgroups");
+        constexpr int kWgPerGroup = kGroupTiles / WAVES;
+        first = (int)a.group_order[blockIdx.x / kWgPerGroup] * kGroupTiles + (int)(blockIdx.x % kWgPerGroup) * WAVES;
+    }
     unsigned long long t_begin = 0;
     if constexpr (SCHED & 2) t_begin = __builtin_readcyclecounter();
-    for (int tile = group * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
+    for (int tile = first + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
         int tx = tile % tiles_x, ty = tile / tiles_x;
         int px = tx * TW + lx;
         int j = ty * TH + ly;
@@ -316,8 +334,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
             uint32_t rgba;
             int2 idd;
             const View &vw = vs.v[blockIdx.y];
-            if constexpr (MODE == 2) full::trace_pixel_full<TRAV>(a, vw, tc_, unorm, px, py, rgba, idd);
-            else trace_pixel<MODE, TRAV>(a, vw, tc_, unorm, px, py, rgba, idd);
+            if constexpr (MODE == 2) full::trace_pixel_full<TRAV>(a, vw, tc_, px, py, rgba, idd);
+            else trace_pixel<MODE, TRAV>(a, vw, tc_, px, py, rgba, idd);
             size_t o = (size_t)(a.compact ? j : py) * (size_t)a.width + (size_t)px;
             if (vw.out_rgba) vw.out_rgba[o] = rgba;
             if (vw.out_id) vw.out_id[o] = idd;
@@ -329,41 +347,42 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
     }
 }
 
-// Feedback scheduling, second half: turns the per-tile ticks of one frame into the workgroup order of the next ones.
+// Feedback scheduling, second half: turns the per-tile ticks of one frame into the group order of the next ones.
 // The hardware starts workgroups in index order, and a launch ends when its last-started, slowest workgroups drain; started
 // heaviest first, the tail consists of the cheapest tiles instead (longest-processing-time-first list scheduling). A
-// workgroup's cost is the maximum over its `waves` tiles; workgroups are bucketed by cost (256 linear buckets up to
-// the frame's maximum) and written out from the heaviest bucket down. One workgroup of 1024 lanes; any permutation is
+// group's cost is the maximum over its kGroupTiles tiles; groups are bucketed by cost (256 linear buckets up to the
+// frame's maximum) and written out from the heaviest bucket down. One workgroup of 1024 lanes; any permutation is
 // correct for the trace kernel, the costs only decide how good it is.
-__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *tile_cost, uint32_t n_tiles, uint32_t waves,
-                                                          uint32_t n_wg, uint32_t *wg_order) {
-    extern __shared__ uint32_t wg_cost[];  // n_wg
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *tile_cost, uint32_t n_tiles, uint32_t n_groups,
+                                                          uint32_t *group_order) {
+    extern __shared__ uint32_t group_cost[];  // n_groups
     __shared__ uint32_t hist[256], top;
     const uint32_t t = threadIdx.x;
     if (t < 256) hist[t] = 0;
     if (t == 0) top = 0;
     __syncthreads();
     uint32_t m = 0;
-    for (uint32_t g = t; g < n_wg; g += 1024) {
+    for (uint32_t g = t; g < n_groups; g += 1024) {
         uint32_t c = 0;
-        for (uint32_t k = 0; k < waves; ++k) {
-            const uint32_t tile = g * waves + k;
+#pragma unroll
+        for (uint32_t k = 0; k < (uint32_t)kGroupTiles; ++k) {
+            const uint32_t tile = g * kGroupTiles + k;
             if (tile < n_tiles) { const uint32_t v = tile_cost[tile]; c = v > c ? v : c; }
         }
-        wg_cost[g] = c;
+        group_cost[g] = c;
         m = c > m ? c : m;
     }
     atomicMax(&top, m);
     __syncthreads();
     const uint32_t shift = top >= 256 ? 24 - (uint32_t)__builtin_clz(top) : 0;  // top >> shift <= 255
-    for (uint32_t g = t; g < n_wg; g += 1024) atomicAdd(&hist[wg_cost[g] >> shift], 1u);
+    for (uint32_t g = t; g < n_groups; g += 1024) atomicAdd(&hist[group_cost[g] >> shift], 1u);
     __syncthreads();
     if (t == 0) {  // hist[b] := first output slot of bucket b, heaviest bucket first
         uint32_t acc = 0;
         for (int b = 255; b >= 0; --b) { const uint32_t n = hist[b]; hist[b] = acc; acc += n; }
     }
     __syncthreads();
-    for (uint32_t g = t; g < n_wg; g += 1024) wg_order[atomicAdd(&hist[wg_cost[g] >> shift], 1u)] = g;
+    for (uint32_t g = t; g < n_groups; g += 1024) group_order[atomicAdd(&hist[group_cost[g] >> shift], 1u)] = g;
 }
 
 // exactness probe for the arithmetic contract: out[i] = op(x[i], y[i])

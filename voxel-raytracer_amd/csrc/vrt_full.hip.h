@@ -151,7 +151,7 @@ VRT_DEV RayS make_ray(F3 o, F3 d, float iof, float w, const float tint[3], float
 }
 
 template <class TRAV>
-__device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, const float *unorm, int px, int py, uint32_t &rgba, int2 &idd) {
+__device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, int px, int py, uint32_t &rgba, int2 &idd) {
     const float kPI = 3.14159265359f;
     const float sky[3] = {0.5f, 0.7f, 1.0f};
     const float kSun = 3.0f;
@@ -170,7 +170,7 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
     int voxel_id = 0;
     int pixel_dist = a.wmax[0] - a.wmin[0];
     F3 gro = scale3(ray_origin, a.voxel_scale);
-    Decoded tv = decode_leaf(unorm, vw.eye0, vw.eye1);  // medium at the eye: looked up once by the dispatcher
+    Decoded tv = decode_leaf(vw.eye0, vw.eye1);  // medium at the eye: looked up once by the dispatcher
     float start_iof = (tv.p[0] > 0.0f && tv.p[0] < 3.0f) ? tv.p[0] : 1.0f;
     float inv_len = 1.0f / __builtin_sqrtf(dot3(ray_dir, ray_dir));
     ray_dir = scale3(ray_dir, inv_len);
@@ -207,8 +207,8 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
         const F3 hp = h.point;
         const F3 hpw{hp.x / a.voxel_scale, hp.y / a.voxel_scale, hp.z / a.voxel_scale};
         r.dim = r.dim + len3(sub3(hpw, r.o)) / a.voxel_scale;
-        Decoded hv = decode_leaf(unorm, h.h0, h.h1);
-        Decoded last = decode_leaf(unorm, h.p0, h.p1);
+        Decoded hv = decode_leaf(h.h0, h.h1);
+        Decoded last = decode_leaf(h.p0, h.p1);
         if (hv.c[3] <= 0.0f) { hv.p[0] = 1.0f; hv.p[1] = 0.0f; hv.p[2] = 0.0f; }
         if (last.c[3] <= 0.0f) {
             if (r.iof > 0.0f) { last.p[0] = 0.0f; last.p[1] = 0.0f; last.p[2] = 0.0f; }
@@ -311,6 +311,7 @@ __global__ void math_probe_full_kernel(int op, const float *x, const float *y, f
         case 12: r = det_powf(a, b); break;
         case 13: { int q; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(q) : "v"(a)); r = (float)q; } break;
         case 14: r = (float)__float_as_uint(a) / 4294967296.0f; break;  // rand(): uint -> float, RNE
+        case 15: r = unorm_of(a); break;                                // must equal a / 255.0f for the 256 byte values
         default: break;
     }
     out[i] = r;

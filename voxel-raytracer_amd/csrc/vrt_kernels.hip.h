@@ -62,6 +62,7 @@ VRT_DEV uint32_t medium_byte(uint32_t w0, uint32_t w1) { return (w0 >> 24) != 0u
 
 template <bool USE_LDS>
 struct Trav {
+    static constexpr bool kStagesLds = USE_LDS;
     struct Ctx {
         const uint2 *lds;      // staged record prefix (USE_LDS)
         uint2 root;

@@ -20,6 +20,7 @@ struct Found {             // deepest node containing the query point
 
 template <bool USE_LDS>
 struct Trav {
+    static constexpr bool kStagesLds = USE_LDS;
     struct Ctx {
         const uint2 *lds;
         uint2 root;

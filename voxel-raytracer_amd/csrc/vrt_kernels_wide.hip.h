@@ -57,6 +57,7 @@ VRT_DEV bool in_world_u(const KArgs &a, I3 p) {  // comp:224-226, as three unsig
 }
 
 struct Trav {
+    static constexpr bool kStagesLds = false;
     struct Ctx {
         uint2 root;
     };
