@@ -340,6 +340,12 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
 
     const int th = 64 / v.tw;
     const long tiles = (long)((width + v.tw - 1) / v.tw) * (long)((n_rows + th - 1) / th);
+    {   // index arithmetic of the prologue without integer divisions where the shapes allow it
+        const unsigned long tiles_x = (unsigned long)((width + v.tw - 1) / v.tw);
+        // q = (n * M) >> 32 with M = floor(2^32 / d) + 1 equals n / d while n * d < 2^32 (the error term n * (M * d - 2^32) stays below 2^32)
+        a.tiles_x_magic = (tiles_x > 1 && (unsigned long)(tiles + 4) * tiles_x < (1ul << 32)) ? (uint32_t)((1ul << 32) / tiles_x + 1) : 0u;
+        a.row_mode = tile_rows >= n_rows ? 1 : ((tile_rows == 8 && th == 8) ? 2 : 0);
+    }
     const int waves = v.block / 64;
     long grid = (tiles + waves - 1) / waves;
     if (v.blocks_per_cu > 0) {

@@ -60,6 +60,9 @@ struct KArgs {
     //   y = row0 + (j / tile_rows) * row_stride + (j % tile_rows)
     int row0, n_rows, tile_rows, row_stride;
     int compact;              // 1: outputs indexed by local row j, 0: by frame row y
+    // the two index divisions of a wave's prologue, prepared by the host (enqueue() in vrt_capi.hip):
+    uint32_t tiles_x_magic;   // floor(2^32 / tiles_x) + 1 when tile / tiles_x == umulhi(tile, magic) for every tile, else 0
+    int row_mode;             // 1: one row tile (y = row0 + j); 2: tile_rows == 8 == tile height (y = row0 + ty * row_stride + ly); 0: divide
     const uint2 *nodes;       // level-ordered records (vrt_layout.h), root = record 0
     uint32_t n_records;
     uint32_t lds_records;     // prefix of `nodes` staged in LDS by each workgroup
@@ -326,11 +329,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
     unsigned long long t_begin = 0;
     if constexpr (SCHED & 2) t_begin = __builtin_readcyclecounter();
     for (int tile = first + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
-        int tx = tile % tiles_x, ty = tile / tiles_x;
+        int tx, ty;
+        if (a.tiles_x_magic) {
+            ty = (int)__umulhi((uint32_t)tile, a.tiles_x_magic);
+            tx = tile - ty * tiles_x;
+        } else {
+            tx = tile % tiles_x;
+            ty = tile / tiles_x;
+        }
         int px = tx * TW + lx;
         int j = ty * TH + ly;
         if (px < a.width && j < a.n_rows) {
-            int py = a.row0 + (j / a.tile_rows) * a.row_stride + (j % a.tile_rows);
+            int py;
+            if (a.row_mode == 1) py = a.row0 + j;
+            else if (a.row_mode == 2 && TH == 8) py = a.row0 + ty * a.row_stride + ly;
+            else py = a.row0 + (j / a.tile_rows) * a.row_stride + (j % a.tile_rows);
             uint32_t rgba;
             int2 idd;
             const View &vw = vs.v[blockIdx.y];
