@@ -236,8 +236,11 @@ SchedState *sched_state(vrt_ctx *c, hipStream_t s, int width, int n_rows, int ro
         (void)hipFree(slot->d_order);
         *slot = SchedState{};
     }
-    if (hipMalloc((void **)&slot->d_cost, (size_t)n_tiles * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void **)&slot->d_order, (size_t)n_groups * sizeof(uint32_t)) != hipSuccess) {
+    // whole groups of ticks; the words past the last tile are never written and must read as zero
+    const size_t cost_bytes = (size_t)n_groups * vrt::kGroupTiles * sizeof(uint32_t);
+    if (hipMalloc((void **)&slot->d_cost, cost_bytes) != hipSuccess ||
+        hipMalloc((void **)&slot->d_order, (size_t)n_groups * sizeof(uint32_t)) != hipSuccess ||
+        hipMemsetAsync(slot->d_cost, 0, cost_bytes, s) != hipSuccess) {
         (void)hipFree(slot->d_cost);
         (void)hipFree(slot->d_order);
         *slot = SchedState{};
@@ -397,7 +400,7 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kSchedMaxGroups * sizeof(uint32_t))));
                 raised = true;
             }
-            hipLaunchKernelGGL(vrt::tile_order_kernel, dim3(1), dim3(1024), lds, s, st->d_cost, st->n_tiles, st->n_groups,
+            hipLaunchKernelGGL(vrt::tile_order_kernel, dim3(1), dim3(1024), lds, s, (const uint4 *)st->d_cost, st->n_groups,
                                st->d_order);
             VRT_HIP(c, hipGetLastError());
             st->valid = true;

@@ -366,34 +366,47 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
 // group's cost is the maximum over its kGroupTiles tiles; groups are bucketed by cost (256 linear buckets up to the
 // frame's maximum) and written out from the heaviest bucket down. One workgroup of 1024 lanes; any permutation is
 // correct for the trace kernel, the costs only decide how good it is.
-__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *tile_cost, uint32_t n_tiles, uint32_t n_groups,
-                                                          uint32_t *group_order) {
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint4 *group_ticks, uint32_t n_groups, uint32_t *group_order) {
+    // group_ticks: the tile_cost words, kGroupTiles per group; the words past the launch's last tile are zero
+    static_assert(kGroupTiles == 4, "one 16-byte load per group");
     extern __shared__ uint32_t group_cost[];  // n_groups
-    __shared__ uint32_t hist[256], top;
+    __shared__ uint32_t hist[256], scan[256], top;
     const uint32_t t = threadIdx.x;
     if (t < 256) hist[t] = 0;
     if (t == 0) top = 0;
     __syncthreads();
     uint32_t m = 0;
-    for (uint32_t g = t; g < n_groups; g += 1024) {
-        uint32_t c = 0;
+    for (uint32_t base = 0; base < n_groups; base += 8 * 1024) {  // eight loads in flight per lane: one round trip per 8192 groups
+        uint4 v[8];
 #pragma unroll
-        for (uint32_t k = 0; k < (uint32_t)kGroupTiles; ++k) {
-            const uint32_t tile = g * kGroupTiles + k;
-            if (tile < n_tiles) { const uint32_t v = tile_cost[tile]; c = v > c ? v : c; }
+        for (uint32_t u = 0; u < 8; ++u) {
+            const uint32_t g = base + u * 1024 + t;
+            v[u] = g < n_groups ? group_ticks[g] : make_uint4(0, 0, 0, 0);
         }
-        group_cost[g] = c;
-        m = c > m ? c : m;
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            const uint32_t g = base + u * 1024 + t;
+            const uint32_t c01 = v[u].x > v[u].y ? v[u].x : v[u].y, c23 = v[u].z > v[u].w ? v[u].z : v[u].w;
+            const uint32_t c = c01 > c23 ? c01 : c23;
+            if (g < n_groups) group_cost[g] = c;
+            m = c > m ? c : m;
+        }
     }
     atomicMax(&top, m);
     __syncthreads();
     const uint32_t shift = top >= 256 ? 24 - (uint32_t)__builtin_clz(top) : 0;  // top >> shift <= 255
     for (uint32_t g = t; g < n_groups; g += 1024) atomicAdd(&hist[group_cost[g] >> shift], 1u);
     __syncthreads();
-    if (t == 0) {  // hist[b] := first output slot of bucket b, heaviest bucket first
-        uint32_t acc = 0;
-        for (int b = 255; b >= 0; --b) { const uint32_t n = hist[b]; hist[b] = acc; acc += n; }
+    // hist[b] := first output slot of bucket b, heaviest bucket first (a suffix sum over the 256 counts)
+    if (t < 256) scan[t] = hist[t];
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        const uint32_t add = (t < 256 && t + off < 256) ? scan[t + off] : 0u;
+        __syncthreads();
+        if (t < 256) scan[t] += add;
+        __syncthreads();
     }
+    if (t < 256) hist[t] = scan[t] - hist[t];
     __syncthreads();
     for (uint32_t g = t; g < n_groups; g += 1024) group_order[atomicAdd(&hist[group_cost[g] >> shift], 1u)] = g;
 }
