@@ -65,7 +65,43 @@ def main():
             if i % 25 == 24:
                 print(name, i + 1, "poses,", frames, "frames,", bad, "mismatches, %.0f s" % (time.time() - t0), flush=True)
     print("fuzz done:", frames, "frames,", pixels, "pixels,", hits, "with a hit,", bad, "mismatches")
-    sys.exit(1 if bad else 0)
+    # second phase: the feedback tile scheduler. Frames large enough to be scheduled (>= 2048 groups of four tiles),
+    # a camera that keeps moving, orders re-derived every 1-3 launches; every frame against the same frame traced
+    # with the scheduler off (which the first phase ties to the oracle).
+    sched_frames = sched_bad = 0
+    n2 = max(10, n // 25)
+    for name, extent in (("dragon", (128, 110, 60)), ("monu9", (100, 120, 100)), ("nature", (128, 160, 128))):
+        w = V.World()
+        assert w.load_vox(os.path.join(ROOT, "tests/golden/maps", name + ".vox"))
+        ctx.upload_octree(*w.flatten())
+        ext = np.array(extent, float)
+        for shape in ((1024, 520), (1352, 760), (1920, 1080)):
+            W, H = shape
+            for mode in (0, 1, 2):
+                pos = ext / 2 + rng.normal(size=3) * ext
+                yaw, pitch = float(rng.uniform(-180, 180)), float(rng.uniform(-60, 60))
+                period = int(rng.integers(1, 4))
+                for i in range(n2):
+                    pos = pos + rng.normal(size=3) * 2.0       # a walk: orders are always a little stale
+                    yaw += float(rng.normal() * 3.0)
+                    if rng.random() < 0.1:                      # and sometimes completely
+                        pos = rng.uniform(0, 1, 3) * ext
+                    ctx.set_camera(*V.camera_block(tuple(float(v) for v in pos), yaw, pitch, W, H)[:3])
+                    ctx.set_tile_scheduling(0)
+                    ref = ctx.dispatch(W, H, mode)
+                    ctx.set_tile_scheduling(period)
+                    got = ctx.dispatch(W, H, mode)
+                    sched_frames += 1
+                    if not (np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])):
+                        sched_bad += 1
+                        print("MISMATCH scheduled", name, shape, "mode", mode, "frame", i, flush=True)
+                    o = ctx.sched_order()
+                    if not np.array_equal(np.sort(o), np.arange(o.size, dtype=np.uint32)) or o.size == 0:
+                        sched_bad += 1
+                        print("BAD ORDER", name, shape, "mode", mode, "frame", i, o.size, flush=True)
+        print(name, "scheduled frames", sched_frames, "mismatches", sched_bad, "%.0f s" % (time.time() - t0), flush=True)
+    print("scheduler fuzz done:", sched_frames, "frames,", sched_bad, "mismatches")
+    sys.exit(1 if (bad or sched_bad) else 0)
 
 
 if __name__ == "__main__":
