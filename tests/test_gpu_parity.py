@@ -291,6 +291,43 @@ def test_denoise_pass_matches_quad_frag_restatement(ctx, V, O, product_scenes):
                 _assert_same(ctx.denoise(rgba, idd), ref, f"denoise radii {W}x{H} kernel {dv}")
 
 
+def test_display_pass_with_feedback_scheduling(V, O, product_scenes):
+    """The display pass under vrt_set_tile_scheduling (its tiles start heaviest first, from measured tile times): frames
+    big enough to be scheduled, the order re-derived every one or two launches and gone stale when the image changes,
+    a tile count that is no multiple of the group size. One frame against the oracle's quad.frag restatement, the
+    others against the unscheduled pass (which the small-frame test above ties to the oracle)."""
+    c = V.Context(0)
+    try:
+        tex, dim = product_scenes["dragon"]
+        c.upload_octree(tex, dim)
+        frames = []
+        for (W, H), pose in [((1056, 544), (63.5, 60.5, 140.5, -90.0, -10.0)), ((1056, 544), (60.3, 64.7, 75.2, -100.0, -25.0)),
+                             ((1920, 1080), (63.5, 60.5, 140.5, -90.0, -10.0))]:
+            ip, iv, cp, _ = V.camera_block(pose[:3], pose[3], pose[4], W, H)
+            c.set_camera(ip, iv, cp)
+            c.set_tile_scheduling(0)
+            rgba, idd = c.dispatch(W, H, 2)
+            frames.append((rgba, idd, c.denoise(rgba, idd)))
+        _assert_same(frames[0][2], O.denoise(frames[0][0], frames[0][1]), "unscheduled display pass 1056x544 vs oracle")
+        for period in (1, 2):
+            c.set_tile_scheduling(period)
+            for k in range(9):
+                rgba, idd, ref = frames[(k // 2) % 2]          # same shape, the image changes every other call
+                _assert_same(c.denoise(rgba, idd), ref, f"scheduled display pass period {period} call {k}")
+            for k in range(3):
+                _assert_same(c.denoise(frames[2][0], frames[2][1]), frames[2][2], f"scheduled display pass 1080p period {period} call {k}")
+        # the fused frame call (trace + display pass on the context's stream, both scheduled)
+        pose = (63.5, 60.5, 140.5, -90.0, -10.0)
+        ip, iv, cp, _ = V.camera_block(pose[:3], pose[3], pose[4], 1920, 1080)
+        c.set_camera(ip, iv, cp)
+        for k in range(4):
+            shown, rgba, idd = c.dispatch_frame(1920, 1080, 2)
+            _assert_same(rgba, frames[2][0], f"fused frame {k} rgba8")
+            _assert_same(shown, frames[2][2], f"fused frame {k} displayed")
+    finally:
+        c.close()
+
+
 def test_record_upload_extension(ctx, V, O, product_scenes):
     """vrt_upload_records: same pixels as the texel path; and a scene beyond the stream's 2^23-texel limit, which
     the texel path must refuse, renders identically under the three traversals (no oracle exists for it)."""

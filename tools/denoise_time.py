@@ -34,8 +34,9 @@ def main():
     d_rgba = torch.from_numpy(rgba.view(np.int32).reshape(H, W)).cuda()
     d_id = torch.from_numpy(idd).cuda()
     outs = []
-    for variant in (1, 0):
+    for variant, period in ((1, 0), (0, 0), (0, 16)):   # one pixel per lane; two; two with feedback tile scheduling
         ctx.set_denoise_variant(variant)
+        ctx.set_tile_scheduling(period)
         d_out = torch.zeros_like(d_rgba)
         torch.cuda.synchronize()
         side = torch.cuda.Stream()      # a null stream handle would select the context's own stream
@@ -50,7 +51,7 @@ def main():
         e1.record(side)
         torch.cuda.synchronize()
         outs.append(d_out.cpu().numpy())
-        print("denoise variant %d  %s %dx%d  %.4f ms" % (variant, name, W, H, e0.elapsed_time(e1) / n))
+        print("denoise variant %d scheduling %2d  %s %dx%d  %.4f ms" % (variant, period, name, W, H, e0.elapsed_time(e1) / n))
     print("variants agree:", all(bool(np.array_equal(outs[0], o)) for o in outs[1:]))
 
 

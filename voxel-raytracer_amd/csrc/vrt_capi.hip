@@ -210,6 +210,8 @@ hipError_t launch_mode(const Variant &v, const vrt::KArgs &a, const vrt::ViewSet
 constexpr long kSchedMinGroups = 2048;   // below ~8 tiles per SIMD there is no tail to shape
 constexpr long kSchedMaxGroups = 36864;  // tile_order_kernel keeps one word per group in LDS (144 KiB of 160)
 constexpr size_t kSchedMaxStates = 8;
+constexpr int kSchedDenoise = 100;              // SchedState::mode of the display pass
+constexpr long kSchedMinDenoiseGroups = 256;    // two workgroups fit a CU: 1,024 tiles are two rounds
 
 // The scheduling state for this launch shape on this stream (created on first use; the least recently used one is
 // recycled when there are kSchedMaxStates). nullptr when device memory for it cannot be had: the launch then runs plain.
@@ -251,6 +253,21 @@ SchedState *sched_state(vrt_ctx *c, hipStream_t s, int width, int n_rows, int ro
     slot->tile_rows = tile_rows; slot->mode = mode; slot->n_tiles = n_tiles; slot->n_groups = n_groups;
     slot->last_use = tick;
     return slot;
+}
+
+// After a measuring launch, on the same stream: reads that launch's ticks, rewrites the order the next launches read.
+int launch_order_kernel(vrt_ctx *c, SchedState *st, hipStream_t s) {
+    static bool raised = false;
+    const size_t lds = (size_t)st->n_groups * sizeof(uint32_t);
+    if (lds > 48 * 1024 && !raised) {
+        VRT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&vrt::tile_order_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kSchedMaxGroups * sizeof(uint32_t))));
+        raised = true;
+    }
+    hipLaunchKernelGGL(vrt::tile_order_kernel, dim3(1), dim3(1024), lds, s, (const uint4 *)st->d_cost, st->n_groups, st->d_order);
+    VRT_HIP(c, hipGetLastError());
+    st->valid = true;
+    return VRT_OK;
 }
 
 // Builds the kernel arguments for local rows [0, n_rows) and enqueues one launch.
@@ -392,18 +409,9 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     if (e != hipSuccess) return fail(c, VRT_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     if (st) {
         ++st->launches;
-        if (measure) {  // same stream: reads this launch's ticks, rewrites the order the next launches read
-            static bool raised = false;
-            const size_t lds = (size_t)st->n_groups * sizeof(uint32_t);
-            if (lds > 48 * 1024 && !raised) {
-                VRT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&vrt::tile_order_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kSchedMaxGroups * sizeof(uint32_t))));
-                raised = true;
-            }
-            hipLaunchKernelGGL(vrt::tile_order_kernel, dim3(1), dim3(1024), lds, s, (const uint4 *)st->d_cost, st->n_groups,
-                               st->d_order);
-            VRT_HIP(c, hipGetLastError());
-            st->valid = true;
+        if (measure) {
+            const int rr = launch_order_kernel(c, st, s);
+            if (rr) return rr;
         }
     }
     if (prof) ++c->prof_count;
@@ -911,7 +919,32 @@ int vrt_denoise(vrt_ctx *c, int width, int height, const void *d_rgba8, const vo
     } else {
         using namespace vrt::denoise;
         const dim3 grid((unsigned)((width + kTW - 1) / kTW), (unsigned)((height + 15) / 16));
-        hipLaunchKernelGGL((denoise_px_kernel<2, 16>), grid, dim3(kTW / 2, 16), 0, s, a);
+        // the trace kernel's feedback scheduling, keyed as mode kSchedDenoise: one tile = one workgroup here
+        a.tiles_x = (int)grid.x;
+        a.n_tiles = (int)(grid.x * grid.y);
+        a.group_order = nullptr;
+        a.tile_cost = nullptr;
+        const long groups = ((long)a.n_tiles + vrt::kGroupTiles - 1) / vrt::kGroupTiles;
+        SchedState *st = nullptr;
+        if (c->sched_period > 0 && groups >= kSchedMinDenoiseGroups && groups <= kSchedMaxGroups)
+            st = sched_state(c, s, width, height, 0, 0, 0, kSchedDenoise, (uint32_t)a.n_tiles, (uint32_t)groups);
+        if (!st) {
+            hipLaunchKernelGGL((denoise_px_kernel<2, 16>), grid, dim3(kTW / 2, 16), 0, s, a);
+        } else {
+            const bool measure = st->launches % (uint64_t)c->sched_period == 0;
+            a.group_order = st->valid ? st->d_order : nullptr;
+            if (measure) {
+                a.tile_cost = st->d_cost;
+                VRT_HIP(c, hipMemsetAsync(st->d_cost, 0, (size_t)groups * vrt::kGroupTiles * sizeof(uint32_t), s));
+            }
+            hipLaunchKernelGGL((denoise_px_kernel<2, 16, true>), dim3((unsigned)(groups * vrt::kGroupTiles)), dim3(kTW / 2, 16), 0, s, a);
+            VRT_HIP(c, hipGetLastError());
+            ++st->launches;
+            if (measure) {
+                const int rr = launch_order_kernel(c, st, s);
+                if (rr) return rr;
+            }
+        }
     }
     VRT_HIP(c, hipGetLastError());
     return VRT_OK;

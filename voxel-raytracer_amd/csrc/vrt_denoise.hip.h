@@ -26,6 +26,11 @@ struct Args {
     const int2 *id;        // (voxelID, dist), W*H
     uint32_t *out;         // packed rgba8, W*H
     int width, height;
+    // feedback scheduling (SCHED flavour of denoise_px_kernel; the trace kernel's scheme, vrt_common.hip.h): tiles are
+    // numbered row-major, a group is kGroupTiles consecutive tiles; either pointer may be null
+    int tiles_x, n_tiles;
+    const uint32_t *group_order;
+    uint32_t *tile_cost;   // atomicMax of the waves' clock ticks; zeroed by the host before a measuring launch
 };
 
 __global__ __launch_bounds__(kTile *kTile) void denoise_kernel(const Args a) {
@@ -336,12 +341,24 @@ __device__ __forceinline__ void fill_unorm(float *s_unorm) {
 // One workgroup per tile. waves_per_eu(2, 2) keeps an instance within 256 registers: the default kernel (PX = 2,
 // TH = 16: four waves per workgroup, two workgroups per CU by LDS) needs two waves to share a SIMD. Without it the
 // compiler, seeing occupancy already limited by LDS, spreads into AGPRs and the second workgroup no longer fits.
-template <int PX, int TH>
+template <int PX, int TH, bool SCHED = false>
 __global__ __launch_bounds__(kTW / PX *TH) __attribute__((amdgpu_waves_per_eu(2, 2))) void denoise_px_kernel(const Args a) {
     __shared__ f4 s_rec[kStride<PX> * (TH + 2 * kMaxR)];
     __shared__ float s_unorm[256];
-    fill_unorm<PX, TH>(s_unorm);
-    tile<PX, TH>(a, blockIdx.x, blockIdx.y, s_rec, s_unorm);
+    if constexpr (!SCHED) {
+        fill_unorm<PX, TH>(s_unorm);
+        tile<PX, TH>(a, blockIdx.x, blockIdx.y, s_rec, s_unorm);
+    } else {  // 1-D grid of whole groups; the tiles of a frame differ by two orders of magnitude (sky: a copy; radius 20: 1,681 taps)
+        int t = (int)blockIdx.x;
+        if (a.group_order) t = (int)a.group_order[blockIdx.x / kGroupTiles] * kGroupTiles + (int)(blockIdx.x % kGroupTiles);
+        if (t >= a.n_tiles) return;
+        const unsigned long long t_begin = a.tile_cost ? __builtin_readcyclecounter() : 0ull;
+        fill_unorm<PX, TH>(s_unorm);
+        const int by = t / a.tiles_x;
+        tile<PX, TH>(a, t - by * a.tiles_x, by, s_rec, s_unorm);
+        if (a.tile_cost && ((threadIdx.y * (kTW / PX) + threadIdx.x) & 63) == 0)
+            atomicMax(&a.tile_cost[t], (uint32_t)(__builtin_readcyclecounter() - t_begin));
+    }
 }
 
 }  // namespace denoise
