@@ -22,6 +22,8 @@ def main():
     tex, dim = w.flatten()
     ctx = V.Context(0)
     ctx.upload_octree(tex, dim)
+    if os.environ.get("SCHED_PERIOD"):   # feedback tile scheduling: 0 = off (default: the library's 16)
+        ctx.set_tile_scheduling(int(os.environ["SCHED_PERIOD"]))
     ip, iv, cp, _ = V.camera_block((63.5, 60.5, 140.5), -90.0, -10.0, W, H)
     ctx.set_camera(ip, iv, cp)
     dev = torch.device("cuda", 0)
