@@ -71,6 +71,11 @@ def main():
     run("explicit order: identity", dev_order(np.arange(n_wg)), ref)
     run("explicit order: heaviest first", dev_order(np.argsort(-wg, kind="stable")), ref)
     run("explicit order: lightest first", dev_order(np.argsort(wg, kind="stable")), ref)
+    run("explicit order: heaviest SUM first", dev_order(np.argsort(-c.reshape(-1, 4).sum(1), kind="stable")), ref)
+    run("explicit order: heaviest MIN first", dev_order(np.argsort(-c.reshape(-1, 4).min(1), kind="stable")), ref)
+    # heaviest first, but the very heaviest 2 % held back a little so they do not all start on the same CUs
+    o = np.argsort(-wg, kind="stable"); k = len(o) // 50
+    run("explicit order: top 2 % interleaved", dev_order(np.concatenate([np.stack([o[:k], o[k:2 * k]], 1).reshape(-1), o[2 * k:]])), ref)
     rng = np.random.default_rng(1)
     run("explicit order: random", dev_order(rng.permutation(n_wg)), ref)
     hw = wg >= np.median(wg)
