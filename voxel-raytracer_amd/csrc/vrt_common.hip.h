@@ -293,13 +293,13 @@ template <class TRAV>
 __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, int px, int py, uint32_t &rgba, int2 &idd);
 }
 
-// WPE also bounds the SCALAR registers: a SIMD admits floor(800 / (ceil(sgprs / 16) * 16 + 16)) waves
-// (MI355X_MICROARCH.md, "Residency") -- 6 with the 106 this kernel takes when unconstrained, whatever its 67 vector
-// registers would allow -- and amdgpu_waves_per_eu(7) makes the compiler stay within the 96 that admit 7.
-
-// One lane per pixel; a wave covers a TW x TH pixel tile (TW*TH == 64) so the 64 rays of a wave
-// stay spatially coherent; workgroups walk tiles with a grid-stride loop.
-// WPE: waves per SIMD the register allocator must leave room for (1 = no constraint beyond BLOCK).
+// One lane per pixel; a wave covers a TW x TH pixel tile (TW*TH == 64) so the 64 rays of a wave stay spatially
+// coherent. One tile per wave (PERSIST: a fixed grid walks the tiles with a grid-stride loop instead).
+// WPE: waves per SIMD the register allocator must leave room for (1 = no constraint beyond BLOCK). It also bounds
+// the SCALAR registers: a SIMD admits floor(800 / (ceil(sgprs / 16) * 16 + 16)) waves (MI355X_MICROARCH.md,
+// "Residency") -- 6 with the 106 this kernel takes when unconstrained, whatever its 67 vector registers would
+// allow -- and amdgpu_waves_per_eu(7) makes the compiler stay within the 96 that admit 7.
+// SCHED: feedback scheduling flavours (KArgs::group_order / tile_cost).
 template <int MODE, class TRAV, int TW, int BLOCK, int WPE = 1, bool PERSIST = false, int SCHED = 0>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) void trace_kernel(const KArgs a, const ViewSet vs) {
     extern __shared__ __attribute__((aligned(16))) uint2 lds_dyn[];
@@ -316,9 +316,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
     const int tiles_y = (a.n_rows + TH - 1) / TH;
     const int n_tiles = tiles_x * tiles_y;
     const int lx = lane % TW, ly = lane / TW;
-    // PERSIST: a fixed grid walks the tiles with a grid-stride loop. Otherwise one tile per wave and no loop:
-    // without the back edge the kernel arguments need not stay live after ray generation, which is worth
-    // ~19 VGPRs (88 -> 69) and two thirds of the SGPR spills on gfx950.
+    // One tile per wave and no loop unless PERSIST: without the back edge the kernel arguments need not stay live
+    // after ray generation, which is worth ~19 VGPRs (88 -> 69) and two thirds of the SGPR spills on gfx950.
     static_assert(!(PERSIST && SCHED), "the scheduled flavours trace one tile per wave");
     int first = blockIdx.x * WAVES;  // first tile of this workgroup
     if constexpr (SCHED & 1) {
