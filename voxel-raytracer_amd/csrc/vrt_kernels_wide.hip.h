@@ -86,7 +86,7 @@ struct Trav {
                     asm volatile("" : "+s"(roots));
 #pragma unroll
                     for (int k = 0; k < 8; ++k)
-                        if ((uint32_t)k < a.n_roots && roots[k] == ridx) { node = roots[8 + k]; found = true; }
+                        if (roots[k] == ridx) { node = roots[8 + k]; found = true; }  // unused slots hold record 0xffffffff
                     if (found) {
                         s = sh;
                         w.anode = node; w.as = sh;
