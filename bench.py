@@ -109,10 +109,11 @@ def main():
                     help="final: traced frames stay sharded in their ranks' HBM (as a one-GPU run keeps them resident); the "
                          "last frame is gathered to rank 0 and assembled inside the timed region. frame: EVERY frame is "
                          "gathered to rank 0 (double-buffered) -- bounded by 12 B/pixel into one GPU's xGMI links")
-    ap.add_argument("--streams", type=int, default=0, choices=[0, 1, 2],
-                    help="HIP streams the frames alternate between (2: the drain of one launch overlaps the start of the "
-                         "next). 0 = 1 at one GPU, where the per-launch duration feeds the roofline and must not be "
-                         "inflated by a neighbour, and 2 with more ranks, where a launch is a fraction of a frame")
+    ap.add_argument("--streams", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help="HIP streams the frames rotate through (the drain of one launch overlaps the start of the next "
+                         "ones). 0 = 1 at one GPU, where the per-launch duration feeds the roofline and must not be "
+                         "inflated by a neighbour, and 4 with more ranks, where a launch is a fraction of a frame (an "
+                         "eighth of a frame: 25.7 us per launch on one stream, 13.7 on two, 9.2 on four)")
     ap.add_argument("--extras", action="store_true",
                     help="one GPU: after the timed region also time the same frames alternating between two streams "
                          "(overlapped_frames) and four per launch (batched_views). Off by default so that a rocprofv3 "
@@ -171,7 +172,7 @@ def main():
     ctx.set_camera(ip, iv, cp)
 
     plan = shd.ShardPlan(W, H, args.tile_rows, rank, world)
-    n_streams = args.streams or (1 if world == 1 else 2)
+    n_streams = args.streams or (1 if world == 1 else 4)
     pipe = shd.FramePipeline(plan, dev, stage_through_host=via_host, gather=args.gather, streams=n_streams)
 
     def step():
@@ -277,7 +278,7 @@ def main():
         launch_ms = ctx.profile_read(n_launch)
         ctx.set_profiling(0)
         last = bufs[((n_launch - 1) & 1) * F + F - 1]
-        same = bool(torch.equal(last, pipe.local[(pipe.frame + 1) % 2].view(-1)[: last.numel()]))
+        same = bool(torch.equal(last, pipe.local[(pipe.frame - 1) % pipe.n_buf].view(-1)[: last.numel()]))
         batched = {"frames_per_launch": F, "value": round(W * H * n_launch * F / e3 / 1e6, 2), "unit": "Mrays/s",
                    "ms_per_step": round(e3 / (n_launch * F) * 1e3, 5), "same_pixels": same,
                    "launch_avg_ms": round(float(launch_ms.mean()), 5) if len(launch_ms) else None}

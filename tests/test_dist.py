@@ -43,11 +43,12 @@ WORKER = textwrap.dedent("""
             frame_rgba, frame_id = plan.frame_views(store)
             assert np.array_equal(frame_rgba.numpy().view(np.uint8).reshape(H, W, 4), full_rgba)
             assert np.array_equal(frame_id.numpy(), full_id)
-        # the pipelines bench.py uses: 5 frames through two buffers; "frame" gathers each one asynchronously,
-        # "final" keeps them sharded and gathers the last one on drain
-        for mode in ("frame", "final"):
-            pipe = shd.FramePipeline(plan, "cpu", gather=mode)
-            for f in range(5):
+        # the pipelines bench.py uses: frames through two to four buffers (one per stream); "frame" gathers each
+        # one asynchronously, "final" keeps them sharded and gathers the last one on drain
+        for mode, n_streams, n_frames in (("frame", 1, 5), ("final", 1, 5), ("frame", 4, 7), ("final", 4, 7), ("final", 3, 2)):
+            pipe = shd.FramePipeline(plan, "cpu", gather=mode, streams=n_streams)
+            assert pipe.n_buf == max(2, n_streams)
+            for f in range(n_frames):
                 k, _, _ = pipe.slot()
                 buf = pipe.local[k]
                 buf.zero_()
@@ -62,8 +63,8 @@ WORKER = textwrap.dedent("""
             pipe.drain()                  # idempotent
             if rank == 0:
                 fr, fi = pipe.frame_views()
-                assert np.array_equal(fr.numpy(), full_rgba.view(np.int32).reshape(H, W) + 4), mode
-                assert np.array_equal(fi.numpy(), full_id - 4), mode
+                assert np.array_equal(fr.numpy(), full_rgba.view(np.int32).reshape(H, W) + (n_frames - 1)), (mode, n_streams)
+                assert np.array_equal(fi.numpy(), full_id - (n_frames - 1)), (mode, n_streams)
     dist.barrier()
     dist.destroy_process_group()
     sys.stdout.write("rank %d ok\\n" % rank); sys.stdout.flush()

@@ -35,7 +35,7 @@ def main():
     g = json.load(open(os.path.join(ROOT, "tests/golden/frames.json")))["frames"]["dragon_1080p/mode0"]
     plan = shd.ShardPlan(W, H, 8, 0, 1)
     for mode in ("final", "frame"):
-        for streams in (1, 2):
+        for streams in (1, 2, 4):
             pipe = shd.FramePipeline(plan, dev, gather=mode, streams=streams, collective=True)
             dist.barrier()
             torch.cuda.synchronize(dev)

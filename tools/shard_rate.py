@@ -30,13 +30,13 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
     for world in (1, 2, 4, 8):
         plan = shd.ShardPlan(W, H, 8, 0, world)
-        bufs = [plan.local_buffer(dev) for _ in range(2)]
+        bufs = [plan.local_buffer(dev) for _ in range(4)]
         ptrs = [plan.pointers(b) for b in bufs]
-        side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        side = [torch.cuda.Stream(dev) for _ in range(4)]
         cam = (ip, iv, cp)
         bufs4 = [plan.local_buffer(dev) for _ in range(8)]
         ptrs4 = [plan.pointers(b) for b in bufs4]
-        for mode in ("one stream", "two streams", "2 views/launch", "4 views/launch"):
+        for mode in ("one stream", "two streams", "three streams", "four streams", "2 views/launch", "4 views/launch"):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             if mode.endswith("launch"):
@@ -45,10 +45,11 @@ def main():
                 for i in range(steps // f):
                     ctx.dispatch_views(W, H, 8, 0, world, 0, sets[i % len(sets)], stream)
             else:
+                ns = {"one": 1, "two": 2, "three": 3, "four": 4}[mode.split()[0]]
                 for i in range(steps):
-                    p = ptrs[i & 1]
+                    p = ptrs[i % max(2, ns)]
                     ctx.dispatch_shard(W, H, 8, 0, world, 0, p[0], p[1],
-                                       stream if mode == "one stream" else side[i & 1].cuda_stream)
+                                       stream if ns == 1 else side[i % ns].cuda_stream)
             t1 = time.perf_counter()
             torch.cuda.synchronize()
             t2 = time.perf_counter()

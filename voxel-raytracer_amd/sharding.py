@@ -88,7 +88,7 @@ def gather_frame(plan, local, gathered, store, index, group=None, stage_through_
 
 
 class FramePipeline:
-    """Two shard buffers per rank; frame i is traced into buffer i % 2.
+    """B = max(2, streams) shard buffers per rank; frame i is traced into buffer i % B (on stream i % streams).
 
     gather="final" (default): frames stay where they were traced -- rank r keeps rows_of[r] of every frame
     resident in its HBM, exactly as the one-GPU run keeps whole frames resident -- and only drain() moves data:
@@ -98,7 +98,7 @@ class FramePipeline:
 
     gather="frame": every frame is delivered to rank 0 (what a single display GPU needs). The gather of frame i
     is issued asynchronously (RCCL runs it on its own stream behind an event) and overlaps the trace of frame
-    i + 1; the only waits are the ones data hazards need: before buffer i % 2 is overwritten by frame i + 2,
+    i + 1; the only waits are the ones data hazards need: before buffer i % B is overwritten by frame i + B,
     gather i must have completed -- at that point rank 0 also scatters frame i into the frame store. A step then
     costs max(trace, gather) once the pipe is full. 12 B/pixel into ONE GPU bounds this mode: at 1080p that is
     21.8 MB x (N-1)/N per frame through rank 0's xGMI links.
@@ -107,32 +107,33 @@ class FramePipeline:
     def __init__(self, plan, device, group=None, stage_through_host=False, gather="final", streams=1, collective=None):
         if gather not in ("final", "frame"):
             raise ValueError("gather must be 'final' or 'frame'")
-        if streams not in (1, 2):
-            raise ValueError("streams must be 1 or 2")
+        if streams not in (1, 2, 3, 4):
+            raise ValueError("streams must be 1 to 4")
         self.plan, self.group, self.via_host, self.mode = plan, group, stage_through_host, gather
         # collective=True runs the gathers through the backend even when there is a single rank (tools/rccl_rehearsal.py)
         self.dist = plan.world > 1 if collective is None else bool(collective)
-        self.local = [plan.local_buffer(device) for _ in range(2)]
+        self.n_buf = nb = max(2, streams)
+        self.local = [plan.local_buffer(device) for _ in range(nb)]
         root = plan.rank == 0
-        n_recv = 2 if gather == "frame" else 1
+        n_recv = nb if gather == "frame" else 1
         self.gathered = [plan.gather_buffer(device) if (root and self.dist) else None for _ in range(n_recv)]
         self.store = plan.frame_store(device) if root else None
         self.index = plan.scatter_index(device) if root else None
-        self.pending = [None, None]   # per slot: None | "resident" | async work handle
+        self.pending = [None] * nb    # per slot: None | "resident" | async work handle
         self.frame = 0
-        # streams=2: the two buffers are traced on two HIP streams, so the drain of one launch (its last, slowest
-        # waves) overlaps the ramp-up of the next; frames i and i+2 share a buffer AND a stream, so they stay ordered.
-        # Worth 13 % at one GPU and 2x at an eighth of a frame per launch (tools/shard_rate.py).
+        # streams > 1: buffer k is traced on HIP stream k, so the drain of one launch (its last, slowest waves) overlaps
+        # the ramp-up of the next ones; frames i and i + B share a buffer AND a stream, so they stay ordered. An eighth
+        # of a 1080p frame takes 25.7 us per launch on one stream, 13.7 on two, 9.2 on four (tools/shard_rate.py).
         self.cuda = torch.device(device).type == "cuda"
-        if self.cuda and streams == 2:
-            self.streams = [torch.cuda.Stream(device), torch.cuda.Stream(device)]
+        if self.cuda and streams > 1:
+            self.streams = [torch.cuda.Stream(device) for _ in range(nb)]
             for st in self.streams:
                 st.wait_stream(torch.cuda.current_stream(device))
         elif self.cuda:
-            self.streams = [torch.cuda.current_stream(device)] * 2
+            self.streams = [torch.cuda.current_stream(device)] * nb
         else:
-            self.streams = [None, None]
-        self.side = self.cuda and streams == 2
+            self.streams = [None] * nb
+        self.side = self.cuda and streams > 1
 
     def stream_handle(self, k):
         """hipStream_t (as int) the frame in slot k must be traced on"""
@@ -141,7 +142,7 @@ class FramePipeline:
     def slot(self):
         """(slot index, rgba pointer, id pointer) of the buffer the NEXT frame must be traced into; makes that
         buffer safe to overwrite first. Trace on stream_handle(slot index)."""
-        k = self.frame % 2
+        k = self.frame % self.n_buf
         self._retire(k)
         p_rgba, p_id = self.plan.pointers(self.local[k])
         return k, p_rgba, p_id
@@ -195,11 +196,13 @@ class FramePipeline:
 
     def drain(self):
         """completes the frames still in flight, oldest first; afterwards rank 0's store holds the newest frame"""
-        newest = (self.frame + 1) % 2
-        for k in ((self.frame % 2), newest):
+        nb = self.n_buf
+        newest = (self.frame - 1) % nb
+        for i in range(nb):                        # slot of frame (self.frame - nb + i): oldest ... newest
+            k = (self.frame + i) % nb
             self._retire(k, final=(k == newest) or self.mode == "frame")
         if self.side:
-            for k in (0, 1):
+            for k in range(nb):
                 self._join(k)
 
     def frame_views(self):
