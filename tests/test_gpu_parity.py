@@ -555,6 +555,11 @@ def test_error_behaviour(V):
     cyc = np.array([1, 0, 0, 0xff] + [0, 0, 0, 0] * 8, np.uint8)
     with pytest.raises(V.VrtError, match="record limit"):
         c.upload_octree(cyc, 3)
+    with pytest.raises(V.VrtError, match="period"):
+        c.set_tile_scheduling(-1)
+    c.set_tile_scheduling(0)
+    c.set_tile_scheduling(16)
+    assert c.sched_order().size == 0      # nothing large enough has been launched: no order yet
     c.close()
 
 
