@@ -505,6 +505,20 @@ def test_feedback_tile_scheduling_never_changes_pixels(V, O, product_scenes):
             rgba, idd = c.dispatch(W, H, 0)
             _assert_same(rgba, ref_rgba, f"after scene change frame {k} rgba8")
             _assert_same(idd, ref_id, f"after scene change frame {k} id/dist")
+        # more launch shapes than the scheduler keeps states for: the least recently used ones are recycled
+        c.upload_octree(tex, dim)
+        pose = poses[0]
+        for k in range(20):
+            W, H = 1024 + 8 * k, 520
+            ip, iv, cp, _ = V.camera_block(pose[:3], pose[3], pose[4], W, H)
+            c.set_camera(ip, iv, cp)
+            c.set_tile_scheduling(0)
+            ref_rgba, ref_id = c.dispatch(W, H, 0)
+            c.set_tile_scheduling(1)
+            for _ in range(2):
+                rgba, idd = c.dispatch(W, H, 0)
+                _assert_same(rgba, ref_rgba, f"shape {k} rgba8")
+                _assert_same(idd, ref_id, f"shape {k} id/dist")
         # two streams alternating frames of one shape (bench.py's pipeline) and a 2-way row shard: a state per stream
         c.upload_octree(tex, dim)
         W, H = 1920, 1080
