@@ -245,7 +245,7 @@ SchedState *sched_state(vrt_ctx *c, hipStream_t s, int width, int n_rows, int ro
         hipMemsetAsync(slot->d_cost, 0, cost_bytes, s) != hipSuccess) {
         (void)hipFree(slot->d_cost);
         (void)hipFree(slot->d_order);
-        *slot = SchedState{};
+        *slot = SchedState{};  // an empty state matches no launch and is the first to be recycled
         (void)hipGetLastError();
         return nullptr;
     }
