@@ -89,6 +89,7 @@ def main():
                     ctx.set_camera(*V.camera_block(tuple(float(v) for v in pos), yaw, pitch, W, H)[:3])
                     ctx.set_tile_scheduling(0)
                     ref = ctx.dispatch(W, H, mode)
+                    ref_shown = ctx.denoise(*ref) if mode == 2 else None
                     ctx.set_tile_scheduling(period)
                     got = ctx.dispatch(W, H, mode)
                     sched_frames += 1
@@ -96,6 +97,9 @@ def main():
                         sched_bad += 1
                         print("MISMATCH scheduled", name, shape, "mode", mode, "frame", i, flush=True)
                     o = ctx.sched_order()
+                    if mode == 2 and not np.array_equal(ctx.denoise(*got), ref_shown):   # the display pass, scheduled too
+                        sched_bad += 1
+                        print("MISMATCH scheduled display pass", name, shape, "frame", i, flush=True)
                     if not np.array_equal(np.sort(o), np.arange(o.size, dtype=np.uint32)) or o.size == 0:
                         sched_bad += 1
                         print("BAD ORDER", name, shape, "mode", mode, "frame", i, o.size, flush=True)
