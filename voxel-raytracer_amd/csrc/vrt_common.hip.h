@@ -179,10 +179,39 @@ VRT_DEV Decoded decode_leaf(uint32_t w0, uint32_t w1) {
     return d;
 }
 
+// The kernel's own arguments, re-read from the kernarg segment (KArgs is trace_kernel's first parameter, so it sits at
+// offset 0). Uniforms that are needed only after the march -- lights, the highlighted voxel, tex_dim -- are fetched
+// through this at shading time instead of living in scalar registers across the traversal loops; the empty asm
+// keeps the compiler from hoisting the loads back above its position.
+typedef const KArgs __attribute__((address_space(4))) *LateArgs;
+VRT_DEV LateArgs late_args() {
+    LateArgs p = (LateArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// The launch's views the same way: ViewSet is the second parameter and follows KArgs at its natural alignment.
+typedef const View __attribute__((address_space(4))) *LateView;
+VRT_DEV LateView late_view() {
+    constexpr size_t kOffset = (sizeof(KArgs) + alignof(ViewSet) - 1) / alignof(ViewSet) * alignof(ViewSet);
+    const char __attribute__((address_space(4))) *p =
+        (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + kOffset + blockIdx.y * sizeof(View);
+    asm volatile("" : "+s"(p));
+    return (LateView)p;
+}
+
+// Where a pixel's two results go: read together with the other late arguments (one scalar-load round trip).
+struct LateOut {
+    uint32_t *out_rgba;
+    int2 *out_id;
+    int width, compact;
+};
+VRT_DEV LateOut late_out(LateArgs la, LateView lv) { return LateOut{lv->out_rgba, lv->out_id, la->width, la->compact}; }
+
 // One pixel: ray generation (comp:624-641), primary-ray pathTrace, packing of the two outputs.
 // TRAV supplies the traversal: march(), shadow(). MODE: 0 primary, 1 primary + shadow ray.
 template <int MODE, class TRAV>
-VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, int px, int py, uint32_t &rgba, int2 &idd) {
+VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, int px, int py, uint32_t &rgba, int2 &idd, LateOut &lo) {
     const float kPI = 3.14159265359f;
     float u = ((float)px / (float)a.width) * 2.0f - 1.0f;
     float v = ((float)py / (float)a.height) * 2.0f - 1.0f;
@@ -207,7 +236,6 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
     float medium_density = tvd.c[3] * 5.0f;
     float mc[3] = {1.0f, 1.0f, 1.0f};
     if (tvd.c[3] > 0.0f) { mc[0] = tvd.c[0]; mc[1] = tvd.c[1]; mc[2] = tvd.c[2]; }
-    float tc[3] = {a.global_light[0], a.global_light[1], a.global_light[2]};
     float fc[3] = {0.0f, 0.0f, 0.0f};
     const float sky[3] = {0.5f, 0.7f, 1.0f};
 
@@ -216,10 +244,37 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
     const uint32_t eye_b = vw.eye1 & 0xffu;
     const uint32_t iof_byte = (eye_b >= 1u && eye_b <= 254u) ? eye_b : 85u;
     bool hit = TRAV::march(a, tc_, gro, ray_dir, start_iof, iof_byte, h, &vw);
+    // The uniforms of the shading stage. With a shadow march still to come they are re-read from the kernarg segment
+    // here, in one scalar-load round trip, so that they do not occupy registers across the traversal (-2 % per
+    // frame); the primary-only kernel is short enough that the round trip costs more than the two spills it saves.
+    constexpr bool kLate = MODE != 0;
+    float l_gl[3] = {0.0f, 0.0f, 0.0f}, l_scale = 0.0f;
+    F3 l_eye{0.0f, 0.0f, 0.0f}, l_light{0.0f, 0.0f, 0.0f};
+    int l_hl[3] = {0, 0, 0}, l_dim = 0;
+    if constexpr (kLate) {
+        const LateArgs la = late_args();
+        const LateView lv_ = late_view();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { l_gl[k] = la->global_light[k]; l_hl[k] = la->highlighted[k]; }
+        l_scale = la->voxel_scale;
+        l_dim = la->tex_dim;
+        l_light = F3{la->light_dir[0], la->light_dir[1], la->light_dir[2]};
+        l_eye = F3{lv_->cam_pos[0], lv_->cam_pos[1], lv_->cam_pos[2]};
+        lo = late_out(la, lv_);
+    }
+    // late copies where they were loaded, the arguments themselves (read where they are used) otherwise
+    const auto gl_ = [&](int k) { if constexpr (kLate) return l_gl[k]; else return a.global_light[k]; };
+    const auto hl_ = [&](int k) { if constexpr (kLate) return l_hl[k]; else return a.highlighted[k]; };
+    const float gl[3] = {gl_(0), gl_(1), gl_(2)};
+    const auto scale_ = [&]() { if constexpr (kLate) return l_scale; else return a.voxel_scale; };
+    const auto dim_ = [&]() { if constexpr (kLate) return l_dim; else return a.tex_dim; };
+    const auto eye_ = [&]() { if constexpr (kLate) return l_eye; else return ray_origin; };  // ray_origin; gro = ray_origin * u_voxelScale
+    const auto light_ = [&]() { if constexpr (kLate) return l_light; else return F3{a.light_dir[0], a.light_dir[1], a.light_dir[2]}; };
+    float tc[3] = {gl[0], gl[1], gl[2]};
     if (!hit) {
         // distanceInMedium is still 0 here, so the absorption branch (comp:482) cannot fire
 #pragma unroll
-        for (int k = 0; k < 3; ++k) fc[k] = fc[k] + a.global_light[k] * sky[k] * tc[k] * 1.0f;
+        for (int k = 0; k < 3; ++k) fc[k] = fc[k] + gl[k] * sky[k] * tc[k] * 1.0f;
     } else {
         // normal = length(hitNormal) > 0 ? hitNormal : (0,1,0)  (comp:497); hitNormal is n on h.axis
         int naxis = h.axis;
@@ -227,10 +282,10 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
         if (!(__builtin_fabsf(h.n) > 0.0f)) { naxis = 1; nval = 1.0f; }
         // x / 1.0f == x: the divisions by u_voxelScale only cost instructions at the reference's scale of 1
         F3 hpw = h.point;
-        if (a.voxel_scale != 1.0f) hpw = F3{h.point.x / a.voxel_scale, h.point.y / a.voxel_scale, h.point.z / a.voxel_scale};
+        if (scale_() != 1.0f) hpw = F3{h.point.x / scale_(), h.point.y / scale_(), h.point.z / scale_()};
         // distanceInMedium only feeds the absorption term, which needs mediumDensity > 0 (comp:501,512)
         float dist_in_medium = 0.0f;
-        if (medium_density > 0.0f) dist_in_medium = 0.0f + len3(sub3(hpw, gro)) / a.voxel_scale;
+        if (medium_density > 0.0f) dist_in_medium = 0.0f + len3(sub3(hpw, scale3(eye_(), scale_()))) / scale_();
         Decoded hv = decode_leaf(h.h0, h.h1);
         Decoded lv = decode_leaf(h.p0, h.p1);
         if (hv.c[3] <= 0.0f) { hv.p[0] = 1.0f; hv.p[1] = 0.0f; hv.p[2] = 0.0f; }
@@ -246,7 +301,7 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
 #pragma unroll
             for (int k = 0; k < 3; ++k) tc[k] = tc[k] * det_expf(kk * (1.0f - mc[k]));
         }
-        if (h.map.x == a.highlighted[0] && h.map.y == a.highlighted[1] && h.map.z == a.highlighted[2]) {
+        if (h.map.x == hl_(0) && h.map.y == hl_(1) && h.map.z == hl_(2)) {
             sc[0] = 1.0f - sc[0]; sc[1] = 1.0f - sc[1]; sc[2] = 1.0f - sc[2]; sc[3] = 1.0f;
         }
         // dot products with an axis normal: (a*0 + b*n) + c*0 == b*n up to the sign of a zero, which neither
@@ -254,17 +309,18 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
         float cosi = comp(ray_dir, naxis) * nval;
         if (cosi > 0.0f) nval = -nval;
         F3 normal{naxis == 0 ? nval : 0.0f, naxis == 1 ? nval : 0.0f, naxis == 2 ? nval : 0.0f};
-        F3 light{a.light_dir[0], a.light_dir[1], a.light_dir[2]};
+        const F3 light = light_();
         float ndotl = fmax_c(nval * comp(light, naxis), 0.0f);
         if (sc[3] >= 1.0f) {  // depth 0, first hit (comp:539-544)
-            int lin = h.map.x + a.tex_dim * (h.map.y + a.tex_dim * h.map.z);
+            const int dim = dim_();
+            int lin = h.map.x + dim * (h.map.y + dim * h.map.z);
             voxel_id = lin * 6 + face_index(h.axis, h.n);
-            pixel_dist = (int)len3(sub3(hpw, ray_origin));
+            pixel_dist = (int)len3(sub3(hpw, eye_()));
         }
         if (sc[3] < 1.0f) {  // translucent first hit: direct-lit fallback (comp:548-553)
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                float direct = a.global_light[k] * ndotl;
+                float direct = gl[k] * ndotl;
                 float lit = sc[k] * direct;
                 fc[k] = fc[k] + tc[k] * lit * 1.0f;
             }
@@ -278,7 +334,7 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
                 if (MODE == 1) lit = TRAV::shadow(a, tc_, add3(h.point, scale3(normal, 2e-3f)), light, h);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    float direct = a.global_light[k] * (float)lit * ndotl;
+                    float direct = gl[k] * (float)lit * ndotl;
                     fc[k] = fc[k] + direct * sc[k] * tc[k] * 1.0f / kPI;
                 }
             }
@@ -290,7 +346,7 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
 
 namespace full {  // MODE 2, defined in vrt_full.hip.h
 template <class TRAV>
-__device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, int px, int py, uint32_t &rgba, int2 &idd);
+__device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, int px, int py, uint32_t &rgba, int2 &idd, LateOut &lo);
 }
 
 // One lane per pixel; a wave covers a TW x TH pixel tile (TW*TH == 64) so the 64 rays of a wave stay spatially
@@ -346,11 +402,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
             uint32_t rgba;
             int2 idd;
             const View &vw = vs.v[blockIdx.y];
-            if constexpr (MODE == 2) full::trace_pixel_full<TRAV>(a, vw, tc_, px, py, rgba, idd);
-            else trace_pixel<MODE, TRAV>(a, vw, tc_, px, py, rgba, idd);
-            size_t o = (size_t)(a.compact ? j : py) * (size_t)a.width + (size_t)px;
-            if (vw.out_rgba) vw.out_rgba[o] = rgba;
-            if (vw.out_id) vw.out_id[o] = idd;
+            LateOut lo;  // MODE 1, 2: the output side of the arguments, re-read after the trace rather than kept in registers across it
+            if constexpr (MODE == 2) full::trace_pixel_full<TRAV>(a, vw, tc_, px, py, rgba, idd, lo);
+            else trace_pixel<MODE, TRAV>(a, vw, tc_, px, py, rgba, idd, lo);
+            if constexpr (MODE == 0) lo = LateOut{vw.out_rgba, vw.out_id, a.width, a.compact};
+            size_t o = (size_t)(lo.compact ? j : py) * (size_t)lo.width + (size_t)px;
+            if (lo.out_rgba) lo.out_rgba[o] = rgba;
+            if (lo.out_id) lo.out_id[o] = idd;
         }
         if constexpr (SCHED & 2) {  // the wave has reconverged: this is the time its slowest ray took
             if (lane == 0) a.tile_cost[tile] = (uint32_t)(__builtin_readcyclecounter() - t_begin);

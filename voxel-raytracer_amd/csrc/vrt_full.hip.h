@@ -151,7 +151,7 @@ VRT_DEV RayS make_ray(F3 o, F3 d, float iof, float w, const float tint[3], float
 }
 
 template <class TRAV>
-__device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, int px, int py, uint32_t &rgba, int2 &idd) {
+__device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, int px, int py, uint32_t &rgba, int2 &idd, LateOut &lo) {
     const float kPI = 3.14159265359f;
     const float sky[3] = {0.5f, 0.7f, 1.0f};
     const float kSun = 3.0f;
@@ -298,6 +298,7 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
     }
     rgba = unorm8(fc[0]) | (unorm8(fc[1]) << 8) | (unorm8(fc[2]) << 16) | (255u << 24);
     idd = make_int2(voxel_id, pixel_dist);
+    lo = late_out(late_args(), late_view());
 }
 
 // exactness probe for the conventions above (ops 10..): out[i] = op(x[i], y[i])
