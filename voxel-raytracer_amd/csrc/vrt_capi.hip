@@ -207,7 +207,7 @@ hipError_t launch_mode(const Variant &v, const vrt::KArgs &a, const vrt::ViewSet
     }
 }
 
-constexpr long kSchedMinGroups = 768;    // an eighth of a 1080p frame (1,013 groups) still gains 4 %; below, the 12 us order kernel costs more
+constexpr long kSchedMinGroups = 768;    // an eighth of a 1080p frame (1,013 groups) still gains 4 %; below, the 9 us order kernel costs more
 constexpr long kSchedMaxGroups = 36864;  // tile_order_kernel keeps one word per group in LDS (144 KiB of 160)
 constexpr size_t kSchedMaxStates = 16;
 constexpr int kSchedDenoise = 100;              // SchedState::mode of the display pass

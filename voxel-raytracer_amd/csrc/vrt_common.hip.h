@@ -427,7 +427,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint4 *group_tic
     // group_ticks: the tile_cost words, kGroupTiles per group; the words past the launch's last tile are zero
     static_assert(kGroupTiles == 4, "one 16-byte load per group");
     extern __shared__ uint32_t group_cost[];  // n_groups
-    __shared__ uint32_t hist[256], scan[256], top;
+    __shared__ uint32_t hist[256], top;
     const uint32_t t = threadIdx.x;
     if (t < 256) hist[t] = 0;
     if (t == 0) top = 0;
@@ -449,21 +449,33 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint4 *group_tic
             m = c > m ? c : m;
         }
     }
-    atomicMax(&top, m);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {  // one atomic per wave, not per lane
+        const uint32_t v = (uint32_t)__shfl_xor((int)m, off);
+        m = v > m ? v : m;
+    }
+    if ((t & 63u) == 0u) atomicMax(&top, m);
     __syncthreads();
     const uint32_t shift = top >= 256 ? 24 - (uint32_t)__builtin_clz(top) : 0;  // top >> shift <= 255
     for (uint32_t g = t; g < n_groups; g += 1024) atomicAdd(&hist[group_cost[g] >> shift], 1u);
     __syncthreads();
-    // hist[b] := first output slot of bucket b, heaviest bucket first (a suffix sum over the 256 counts)
-    if (t < 256) scan[t] = hist[t];
-    __syncthreads();
-    for (uint32_t off = 1; off < 256; off <<= 1) {
-        const uint32_t add = (t < 256 && t + off < 256) ? scan[t + off] : 0u;
-        __syncthreads();
-        if (t < 256) scan[t] += add;
-        __syncthreads();
+    // hist[b] := first output slot of bucket b, heaviest bucket first: a suffix sum over the 256 counts, done by
+    // the first wave alone (lane l owns buckets 4l .. 4l+3) so that it costs one barrier instead of sixteen
+    if (t < 64) {
+        const uint32_t h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
+        const uint32_t own = h0 + h1 + h2 + h3;
+        uint32_t incl = own;  // becomes the sum over lanes >= t
+#pragma unroll
+        for (uint32_t off = 1; off < 64; off <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_down((int)incl, off);
+            if (t + off < 64) incl += v;
+        }
+        const uint32_t above = incl - own;  // everything in heavier lanes
+        hist[4 * t + 3] = above;
+        hist[4 * t + 2] = above + h3;
+        hist[4 * t + 1] = above + h3 + h2;
+        hist[4 * t] = above + h3 + h2 + h1;
     }
-    if (t < 256) hist[t] = scan[t] - hist[t];
     __syncthreads();
     for (uint32_t g = t; g < n_groups; g += 1024) group_order[atomicAdd(&hist[group_cost[g] >> shift], 1u)] = g;
 }
