@@ -10,7 +10,7 @@ from conftest import MAPS
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = list(range(20))
+VARIANTS = list(range(21))
 
 
 @pytest.fixture(scope="module")

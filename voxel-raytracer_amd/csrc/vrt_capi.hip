@@ -55,6 +55,7 @@ const Variant kVariants[] = {
     /*17*/ {3, false, 8, 64, 0, 0, 8},
     /*18*/ {3, false, 16, 256, 0, 0, 1},
     /*19*/ {3, false, 8, 64, 0, 0, 7},
+    /*20*/ {3, false, 8, 64, 0, 0, 6},  // variant 0 without its per-mode choice of waves per SIMD
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
