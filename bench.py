@@ -118,9 +118,12 @@ def main():
                     help="one GPU: after the timed region also time the same frames rotating through four streams "
                          "(overlapped_frames) and four per launch (batched_views). Off by default so that a rocprofv3 "
                          "kernel trace of the default command holds the timed region's launches only")
-    ap.add_argument("--sched-period", type=int, default=16,
+    ap.add_argument("--sched-period", type=int, default=-1,
                     help="feedback tile scheduling (vrt_set_tile_scheduling): every n-th launch of a shape measures its tiles "
-                         "and the following ones start them heaviest first; 0 = off (row-major starts). 16 is the library default")
+                         "and the following ones start them heaviest first; 0 = off (row-major starts). Default: the "
+                         "library's 16 up to two ranks; off from four ranks on, where a launch is a quarter of a frame or "
+                         "less and four overlapping streams already fill its tail (tools/shard_rate.py: 17.6 vs 17.9 us at "
+                         "a quarter, 8.9 vs 9.2 us at an eighth)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured path); gloo only rehearses the N>1 code path on a "
                          "box whose ranks share one GPU (collective staged through host memory)")
@@ -134,6 +137,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.sched_period < 0:
+        args.sched_period = 16 if world <= 2 else 0
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
