@@ -72,6 +72,7 @@ struct SchedState {
     uint32_t n_tiles = 0, n_groups = 0;
     uint32_t *d_cost = nullptr, *d_order = nullptr;
     bool valid = false;        // d_order holds an order
+    float cam[6] = {0, 0, 0, 0, 0, 0};  // eye and viewing direction of the launch the order was measured on (trace states)
     uint64_t launches = 0;
     uint64_t last_use = 0;
 };
@@ -256,6 +257,21 @@ SchedState *sched_state(vrt_ctx *c, hipStream_t s, int width, int n_rows, int ro
     return slot;
 }
 
+// An order measured from one pose says little about a frame from a very different one: re-measure at once, instead of
+// waiting out the period, when the eye has moved by more than 16 world units or the view has turned by more than ~8
+// degrees since the order was taken (a cut, a teleport; ordinary camera motion stays far below both per period).
+bool camera_jumped(const float was[6], const float now[6]) {
+    float d2 = 0.0f, dot = 0.0f, n0 = 0.0f, n1 = 0.0f;
+    for (int k = 0; k < 3; ++k) {
+        d2 += (now[k] - was[k]) * (now[k] - was[k]);
+        dot += now[3 + k] * was[3 + k];
+        n0 += was[3 + k] * was[3 + k];
+        n1 += now[3 + k] * now[3 + k];
+    }
+    if (!(d2 <= 16.0f * 16.0f)) return true;           // also true for NaN
+    return !(dot * dot >= 0.98f * n0 * n1 && dot >= 0.0f);  // cos(8 deg)^2 = 0.98
+}
+
 // After a measuring launch, on the same stream: reads that launch's ticks, rewrites the order the next launches read.
 int launch_order_kernel(vrt_ctx *c, SchedState *st, hipStream_t s) {
     static bool raised = false;
@@ -388,7 +404,11 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     } else if (sched_kernel && c->sched_period > 0 && groups >= kSchedMinGroups && groups <= kSchedMaxGroups) {
         st = sched_state(c, s, width, n_rows, row0, row_stride, tile_rows, mode, (uint32_t)tiles, (uint32_t)groups);
         if (st) {
-            measure = st->launches % (uint64_t)c->sched_period == 0;
+            // eye = invView's translation column, viewing direction = minus its third column (column-major)
+            const float *iv = vs.v[0].inv_view;
+            const float now[6] = {iv[12], iv[13], iv[14], -iv[8], -iv[9], -iv[10]};
+            measure = st->launches % (uint64_t)c->sched_period == 0 || (st->valid && camera_jumped(st->cam, now));
+            if (measure) std::memcpy(st->cam, now, sizeof now);
             a.group_order = st->valid ? st->d_order : nullptr;
             a.tile_cost = measure ? st->d_cost : nullptr;
         }
