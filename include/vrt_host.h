@@ -81,8 +81,11 @@ int vrth_encode_vox(int sx, int sy, int sz, const uint8_t *xyzi, size_t n, const
 /* deterministic synthetic scenes:
  *  config 1 "custom.vox" stand-in: 64^3 model, floor slab + sphere -> malloc'd .vox bytes */
 int vrth_make_custom_vox(uint8_t **out, size_t *out_len);
-/*  config 4 procedural terrain inserted straight into the world (size x size columns) */
-int vrth_world_fill_terrain(vrth_world *w, int size, int seed);
+/*  config 4: the reference's commented-out terrain generator (src/main.cpp:487-503) over a height field given as
+ *  data (size_x * size_z uint16, row z, column x): columns x in [x0, x0+nx), z in [z0, z0+nz) are filled for
+ *  y in [max(floor_y, h - band), h) -- two lowest voxels STONE, top one DIRT, the rest GRASS (main.cpp:220-259) */
+int vrth_world_fill_heights(vrth_world *w, const uint16_t *heights, int size_x, int size_z, int x0, int z0, int nx, int nz,
+                            int band, int floor_y);
 
 uint64_t vrth_fnv1a64(const uint8_t *p, size_t n);
 const char *vrth_version(void);

@@ -339,3 +339,34 @@ uint64_t o_fnv1a64(const uint8_t *p, size_t n) {
     for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
     return h;
 }
+
+/* src/main.cpp:487-503 (the commented-out terrain generator) over a height field given as data, scaled as
+ * columns x in [x0, x0+nx), z in [z0, z0+nz); voxels for y in [max(floor_y, h - band), h);
+ * loop order and material tests as written there: `if (h == 20 || h == 21) STONE; else if (h == height - 1) DIRT;
+ * else GRASS` with 20 -> the column's lower end. Materials voxels[] = {3,0,0} for all three (main.cpp:220-226),
+ * colours voxelColors[] GRASS (80,180,60), DIRT (100,70,40), STONE (160,160,160), alpha 255 (main.cpp:247-253);
+ * ColorRGBA = R<<24 | G<<16 | B<<8 | A (color.c:9-12). */
+int o_fill_heights(o_octree *t, const uint16_t *heights, int size_x, int size_z, int x0, int z0, int nx, int nz,
+                   int band, int floor_y) {
+    if (!t || !heights || size_x < 1 || size_z < 1 || band < 1 || x0 < 0 || z0 < 0 || nx < 0 || nz < 0 ||
+        x0 + nx > size_x || z0 + nz > size_z)
+        return -1;
+    const uint32_t grass = (80u << 24) | (180u << 16) | (60u << 8) | 255u;
+    const uint32_t dirt = (100u << 24) | (70u << 16) | (40u << 8) | 255u;
+    const uint32_t stone = (160u << 24) | (160u << 16) | (160u << 8) | 255u;
+    for (int i = z0; i < z0 + nz; i++)
+        for (int j = x0; j < x0 + nx; j++) {
+            const int height = heights[(size_t)i * (size_t)size_x + (size_t)j];
+            const int lo = height - band > floor_y ? height - band : floor_y;
+            for (int h = lo; h < height; h++) {
+                o_voxel_obj v;
+                v.coord.x = j; v.coord.y = h; v.coord.z = i;
+                v.voxel.refraction = 3.0f; v.voxel.illumination = 0.0f; v.voxel.k = 0.0f;
+                if (h == lo || h == lo + 1) v.color = stone;
+                else if (h == height - 1) v.color = dirt;
+                else v.color = grass;
+                o_octree_insert(t, v);
+            }
+        }
+    return 0;
+}

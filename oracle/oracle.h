@@ -59,6 +59,9 @@ o_octree *o_octree_ray_cast(o_octree *root, o_vec3 origin, o_vec3 dir,
                             o_vec3 world_min, o_vec3 world_max);
 /* tex_dim = ceil(cbrt(texels)), min 1 (src/main.cpp:265-268) */
 uint32_t o_tex_dim_for(size_t texels);
+/* src/main.cpp:487-503 terrain generator over a height field given as data (config 4) */
+int o_fill_heights(o_octree *t, const uint16_t *heights, int size_x, int size_z, int x0, int z0, int nx, int nz,
+                   int band, int floor_y);
 
 /* ---------------- .vox loader (src/voxReader.cpp:215-418) ---------------- */
 /* Parses a MagicaVoxel file held in memory and inserts into `tree` exactly as

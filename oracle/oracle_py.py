@@ -82,6 +82,7 @@ def lib():
         L.o_octree_texture.argtypes = [C.POINTER(Octree), C.POINTER(C.c_size_t), C.c_size_t]
         L.o_octree_ray_cast.restype = C.POINTER(Octree)
         L.o_octree_ray_cast.argtypes = [C.POINTER(Octree), Vec3, Vec3, Vec3, Vec3]
+        L.o_fill_heights.argtypes = [C.POINTER(Octree), C.c_void_p] + [C.c_int] * 8
         L.o_tex_dim_for.restype = C.c_uint32
         L.o_tex_dim_for.argtypes = [C.c_size_t]
         L.o_load_vox_mem.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Octree), C.c_int, C.c_int, C.c_int,
@@ -127,6 +128,13 @@ def flatten(tree):
     arr = np.ctypeslib.as_array(p, shape=(sz.value,)).copy()
     L.free(p)
     return arr, int(dim)
+
+
+def fill_heights(tree, heights, x0, z0, nx, nz, band=8, floor_y=20):
+    """config 4 terrain (src/main.cpp:487-503 over a uint16 height field [size_z, size_x]) into `tree`"""
+    h = np.ascontiguousarray(heights, dtype=np.uint16)
+    if lib().o_fill_heights(tree, h.ctypes.data, h.shape[1], h.shape[0], x0, z0, nx, nz, band, floor_y) != 0:
+        raise ValueError("o_fill_heights: bad arguments")
 
 
 def load_vox(path_or_bytes, offset=(0, 0, 0)):

@@ -36,7 +36,7 @@ def V():
 
 @pytest.fixture(scope="session")
 def golden():
-    return {n: json.load(open(os.path.join(GOLDEN, n + ".json"))) for n in ("flatten", "camera", "frames")}
+    return {n: json.load(open(os.path.join(GOLDEN, n + ".json"))) for n in ("flatten", "camera", "frames", "terrain")}
 
 
 @pytest.fixture(scope="session")
@@ -48,7 +48,18 @@ def product_scenes(V):
         assert w.load_vox(os.path.join(MAPS, m + ".vox"))
         out[m] = w.flatten()
         w.close()
+    out["terrain"] = terrain_world(V).flatten()
     return out
+
+
+def terrain_world(V, window=None):
+    """BASELINE config 4 built by the PRODUCT host library: tests/golden/terrain.json over terrain_heights.npz"""
+    t = json.load(open(os.path.join(GOLDEN, "terrain.json")))
+    wd = window or t["window"]
+    w = V.World()
+    w.fill_heights(np.load(os.path.join(GOLDEN, "terrain_heights.npz"))["heights"], wd["x0"], wd["z0"], wd["nx"], wd["nz"],
+                   t["band"], t["floor"])
+    return w
 
 
 def random_voxels(rng, n, lo, hi, n_colors=5):

@@ -30,6 +30,10 @@ FRAMES = [
     ("nature_200x112", "nature", 200, 112, (60.5, 80.5, 200.5, -90.0, -20.0), (0, 1, 2)),
     ("dragon_inside_101x67", "dragon", 101, 67, (60.3, 30.7, 25.2, 37.0, 12.0), (0, 1, 2)),
     ("dragon_720p_full", "dragon", 1280, 720, (63.5, 60.5, 140.5, -90.0, -10.0), (2,)),
+    ("dragon_1080p_full", "dragon", 1920, 1080, (63.5, 60.5, 140.5, -90.0, -10.0), (2,)),
+    # BASELINE config 4: the height-field terrain of tests/golden/terrain.json (make_terrain.py), its frozen pose
+    ("terrain_1080p", "terrain", 1920, 1080, None, (0, 1)),
+    ("terrain_240x136", "terrain", 240, 136, None, (0, 1, 2)),
 ]
 
 
@@ -48,13 +52,25 @@ def main():
     json.dump({"source": "SURVEY.md 8(c) (reference host code); re-derived by oracle/", "maps": flat},
               open(os.path.join(HERE, "flatten.json"), "w"), indent=1)
 
+    import numpy as np
+    terr = json.load(open(os.path.join(HERE, "terrain.json")))
+    t = O.new_tree()
+    wd = terr["window"]
+    O.fill_heights(t, np.load(os.path.join(HERE, "terrain_heights.npz"))["heights"], wd["x0"], wd["z0"], wd["nx"], wd["nz"],
+                   terr["band"], terr["floor"])
+    scenes["terrain"] = O.flatten(t)
+    if "%016x" % O.fnv1a64(scenes["terrain"][0]) != terr["fnv1a64"]:
+        raise SystemExit("terrain: flatten hash differs from terrain.json (run make_terrain.py)")
+
     frames = {}
     for name, m, W, H, pose, modes in FRAMES:
+        if pose is None:
+            pose = tuple(terr["pose"])
         tex, dim = scenes[m]
         (ip, iv, cp), _ = O.camera_ubo(pose[:3], pose[3], pose[4], W, H)
         s = O.make_scene(tex, dim, ip, iv, cp)
         for mode in modes:
-            rgba, idd, fm, st = O.render(s, W, H, mode, want_fetch_map=name.endswith('1080p'))
+            rgba, idd, fm, st = O.render(s, W, H, mode, want_fetch_map=name.endswith('1080p') or name.endswith('1080p_full'))
             frames[f"{name}/mode{mode}"] = {
                 "map": m, "width": W, "height": H, "pose": list(pose), "mode": mode,
                 "rgba_fnv1a64": "%016x" % O.fnv1a64(rgba), "id_dist_fnv1a64": "%016x" % O.fnv1a64(idd),

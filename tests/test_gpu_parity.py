@@ -10,7 +10,7 @@ from conftest import MAPS
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = list(range(21))
+VARIANTS = list(range(25))
 
 
 @pytest.fixture(scope="module")
@@ -119,7 +119,8 @@ def test_small_frames_vs_oracle_and_golden(ctx, V, O, golden, product_scenes, ke
 
 
 @pytest.mark.parametrize("key", ["dragon_1080p/mode0", "dragon_1080p/mode1", "monu9_720p/mode0", "monu9_720p/mode1",
-                                 "dragon_default_720p/mode0", "nature_4k/mode1", "dragon_720p_full/mode2"])
+                                 "dragon_default_720p/mode0", "nature_4k/mode1", "dragon_720p_full/mode2",
+                                 "dragon_1080p_full/mode2", "terrain_1080p/mode0", "terrain_1080p/mode1"])
 def test_full_size_frames_match_committed_hashes(ctx, V, golden, product_scenes, key):
     """BASELINE.json sizes: the oracle's frame hashes were committed by tests/golden/make_golden.py."""
     g = golden["frames"]["frames"][key]
@@ -226,16 +227,20 @@ def test_world_with_eight_wide_roots_and_a_refused_one(ctx, V, O):
     ctx.set_params(ctx.default_params())
 
 
-def test_procedural_terrain_config4(ctx, V, O):
-    """BASELINE config 4 stand-in: 1024x1024 heightfield shell (6.7 M texels, close to the 2^23 pointer limit)."""
-    w = V.World()
-    w.fill_terrain(1024, 1337)
-    tex, dim = w.flatten()
+def test_procedural_terrain_config4(ctx, V, O, golden, product_scenes):
+    """BASELINE config 4: the reference's terrain generator (src/main.cpp:487-503) over the height field its own
+    FastNoiseLite.h produces (tests/golden/terrain.json; 7.6 M texels, close to the 2^23 pointer limit), small frame
+    against the live oracle; the 1920x1080 frames are in test_full_size_frames_match_committed_hashes."""
+    tex, dim = product_scenes["terrain"]
+    t = golden["terrain"]
+    assert tex.size // 4 == t["texels"] and dim == t["tex_dim"] and "%016x" % V.fnv1a64(tex) == t["fnv1a64"]
     assert 4_000_000 < tex.size // 4 < 2 ** 23
-    W, H = 160, 90
-    cam = _setup(ctx, V, tex, dim, (512.5, 420.5, 1000.5, -90.0, -20.0), W, H)
+    W, H = 240, 136
+    cam = _setup(ctx, V, tex, dim, t["pose"], W, H)
     for mode in (0, 1, 2):
         ref_rgba, ref_id, st = _oracle_frame(O, tex, dim, cam, W, H, mode)
+        g = golden["frames"]["frames"][f"terrain_240x136/mode{mode}"]
+        assert "%016x" % O.fnv1a64(ref_rgba) == g["rgba_fnv1a64"] and "%016x" % O.fnv1a64(ref_id) == g["id_dist_fnv1a64"]
         assert st["hits"] > 0.3 * W * H
         for v in (0, 1, 4):
             ctx.set_variant(v)

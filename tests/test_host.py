@@ -20,6 +20,44 @@ def test_flatten_is_byte_identical_to_reference_hashes(V, golden, product_scenes
         assert "%016x" % V.fnv1a64(tex) == g["fnv1a64"]
 
 
+def test_terrain_config4_flatten_matches_oracle_and_fixture(V, O, golden, product_scenes):
+    """BASELINE config 4: product build + flatten of the height-field terrain == the oracle's == tests/golden/terrain.json;
+    the height field itself is the output of the reference's own FastNoiseLite.h (re-derived when the reference is here)."""
+    import json
+    import subprocess
+    from conftest import GOLDEN, ROOT
+    t = golden["terrain"]
+    h = np.load(os.path.join(GOLDEN, "terrain_heights.npz"))["heights"]
+    assert h.dtype == np.uint16 and h.shape == (t["generator"]["size"],) * 2
+    assert (int(h.min()), int(h.max())) == (t["generator"]["min"], t["generator"]["max"])
+    tex, dim = product_scenes["terrain"]
+    assert tex.size // 4 == t["texels"] < t["texel_limit"] and dim == t["tex_dim"]
+    assert "%016x" % V.fnv1a64(tex) == t["fnv1a64"]
+    tree = O.new_tree()
+    wd = t["window"]
+    O.fill_heights(tree, h, wd["x0"], wd["z0"], wd["nx"], wd["nz"], t["band"], t["floor"])
+    otex, odim = O.flatten(tree)
+    O.lib().o_octree_delete(tree)
+    assert odim == dim and np.array_equal(otex, tex)
+    # a different window and band through both builders (ragged edges, floor clamp)
+    w2 = V.World()
+    w2.fill_heights(h, 3, 1000, 21, 24, 5, 250)
+    t2 = O.new_tree()
+    O.fill_heights(t2, h, 3, 1000, 21, 24, 5, 250)
+    assert np.array_equal(w2.flatten()[0], O.flatten(t2)[0])
+    O.lib().o_octree_delete(t2)
+    with pytest.raises(V.VrtError):
+        w2.fill_heights(h, 1000, 0, 100, 1)
+    w2.close()
+    ref_noise = os.path.join(ROOT, "oracle", "_ref", "ref_noise")
+    if os.path.isdir("/root/reference/include") and os.path.exists(ref_noise):
+        tmp = os.path.join(os.environ.get("TMPDIR", "/tmp"), "terrain_check.u16")
+        g = t["generator"]
+        info = json.loads(subprocess.check_output([ref_noise, tmp, str(g["size"]), str(g["amp"]), str(g["seed"])]))
+        assert np.array_equal(np.fromfile(tmp, dtype="<u2").reshape(h.shape), h) and info["max"] == g["max"]
+        os.remove(tmp)
+
+
 def test_camera_block_bits(V, golden):
     for c in golden["camera"]["cases"]:
         ip, iv, cp, fr = V.camera_block([_f(x) for x in c["pos"]], _f(c["yaw"]), _f(c["pitch"]), c["width"], c["height"])

@@ -4,6 +4,7 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
 import vrt_import  # noqa: E402
 
 V = vrt_import.vrt()
@@ -13,12 +14,8 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ctx = V.Context(0)
     for name in sys.argv[1:] or ["dragon", "monu9", "nature", "terrain"]:
-        w = V.World()
         t0 = time.perf_counter()
-        if name == "terrain":
-            w.fill_terrain(1024, 1)
-        else:
-            assert w.load_vox(os.path.join(root, "tests/golden/maps", name + ".vox"))
+        w = bench.load_world(V, name)
         t1 = time.perf_counter()
         tex, dim = w.flatten()
         t2 = time.perf_counter()

@@ -25,11 +25,8 @@ def main():
     ap.add_argument("--modes", default="0,1")
     args = ap.parse_args()
     V = vrt_import.vrt()
-    w = V.World()
-    if args.map == "terrain":
-        w.fill_terrain(1024, 1337)
-    else:
-        assert w.load_vox(os.path.join(ROOT, "tests/golden/maps", args.map + ".vox"))
+    import bench
+    w = bench.load_world(V, args.map)
     tex, dim = w.flatten()
     W, H = args.width, args.height
     p = POSES[args.map]

@@ -91,7 +91,7 @@ def host_lib():
         L.vrth_encode_vox.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
                                       C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.vrth_make_custom_vox.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
-        L.vrth_world_fill_terrain.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.vrth_world_fill_heights.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 8
         L.vrth_fnv1a64.restype = C.c_uint64
         L.vrth_fnv1a64.argtypes = [C.c_void_p, C.c_size_t]
         L.vrth_version.restype = C.c_char_p
@@ -245,9 +245,11 @@ class World:
         L.vrth_free(p)
         return arr, int(d.value)
 
-    def fill_terrain(self, size=1024, seed=1337):
-        if host_lib().vrth_world_fill_terrain(self._h, size, seed) != 0:
-            raise VrtError("vrth_world_fill_terrain failed")
+    def fill_heights(self, heights, x0, z0, nx, nz, band=8, floor_y=20):
+        """config 4 terrain: the reference's generator (src/main.cpp:487-503) over a uint16 height field [size_z, size_x]"""
+        h = np.ascontiguousarray(heights, dtype=np.uint16)
+        if host_lib().vrth_world_fill_heights(self._h, h.ctypes.data, h.shape[1], h.shape[0], x0, z0, nx, nz, band, floor_y) != 0:
+            raise VrtError("vrth_world_fill_heights failed")
 
 
 def camera_block(pos, yaw, pitch, width, height):

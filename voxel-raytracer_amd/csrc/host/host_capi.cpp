@@ -28,38 +28,6 @@ inline uint32_t fbits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 void put_u32(std::vector<uint8_t> &b, uint32_t v) { for (int i = 0; i < 4; ++i) b.push_back((uint8_t)(v >> (8 * i))); }
 void put_tag(std::vector<uint8_t> &b, const char *t) { b.insert(b.end(), t, t + 4); }
 
-// classic gradient noise on a 256-periodic lattice (own implementation; the
-// reference only carries a commented-out FastNoiseLite heightmap, src/main.cpp:487-503)
-struct Noise2D {
-    uint8_t perm[512];
-    explicit Noise2D(uint32_t seed) {
-        uint8_t p[256];
-        for (int i = 0; i < 256; ++i) p[i] = (uint8_t)i;
-        uint32_t s = seed * 747796405u + 2891336453u;
-        for (int i = 255; i > 0; --i) {
-            s = s * 1664525u + 1013904223u;
-            int j = (int)((s >> 8) % (uint32_t)(i + 1));
-            uint8_t t = p[i]; p[i] = p[j]; p[j] = t;
-        }
-        for (int i = 0; i < 512; ++i) perm[i] = p[i & 255];
-    }
-    static double fade(double t) { return t * t * t * (t * (t * 6.0 - 15.0) + 10.0); }
-    static double grad(int h, double x, double y) {
-        switch (h & 7) {
-            case 0: return x + y; case 1: return x - y; case 2: return -x + y; case 3: return -x - y;
-            case 4: return x; case 5: return -x; case 6: return y; default: return -y;
-        }
-    }
-    double at(double x, double y) const {
-        const int xi = (int)floor(x) & 255, yi = (int)floor(y) & 255;
-        const double xf = x - floor(x), yf = y - floor(y), u = fade(xf), v = fade(yf);
-        const int aa = perm[perm[xi] + yi], ab = perm[perm[xi] + yi + 1];
-        const int ba = perm[perm[xi + 1] + yi], bb = perm[perm[xi + 1] + yi + 1];
-        const double x1 = grad(aa, xf, yf) + u * (grad(ba, xf - 1, yf) - grad(aa, xf, yf));
-        const double x2 = grad(ab, xf, yf - 1) + u * (grad(bb, xf - 1, yf - 1) - grad(ab, xf, yf - 1));
-        return (x1 + v * (x2 - x1)) * 0.7071067811865476;  // ~[-1,1]
-    }
-};
 }  // namespace
 
 extern "C" {
@@ -357,33 +325,25 @@ int vrth_make_custom_vox(uint8_t **out, size_t *out_len) {
     return vrth_encode_vox(64, 64, 64, xyzi.data(), xyzi.size() / 4, pal, out, out_len);
 }
 
-// Config 4 stand-in: size x size heightfield as a watertight one-voxel shell (each column reaches down to its
-// lowest neighbour; grass on top, dirt, stone; colours/materials of src/main.cpp:220-259). A shell, not a
-// filled band: the flattened tree of a 1024^2 field must stay under the format's 2^23-texel pointer limit.
-int vrth_world_fill_terrain(vrth_world *w, int size, int seed) {
-    if (!w || size < 1 || size > 1024) return -1;
-    const Noise2D noise((uint32_t)seed);
-    std::vector<int> height((size_t)size * size);
-    for (int z = 0; z < size; ++z)
-        for (int x = 0; x < size; ++x) {
-            const double n = 0.6 * noise.at(x * 0.01, z * 0.01) + 0.35 * noise.at(x * 0.031, z * 0.031) + 0.05 * noise.at(x * 0.09, z * 0.09);
-            int h = (int)((n + 1.0) * 33.0 * 4.0) + 120;
-            height[(size_t)z * size + x] = h > 1000 ? 1000 : h;
-        }
-    for (int z = 0; z < size; ++z)
-        for (int x = 0; x < size; ++x) {
-            const int h = height[(size_t)z * size + x];
-            int lo = h - 1;  // watertight shell: reach down to the lowest 4-neighbour column top
-            const int nx[4] = {x - 1, x + 1, x, x}, nz[4] = {z, z, z - 1, z + 1};
-            for (int k = 0; k < 4; ++k)
-                if (nx[k] >= 0 && nx[k] < size && nz[k] >= 0 && nz[k] < size) {
-                    const int hn = height[(size_t)nz[k] * size + nx[k]];
-                    if (hn < lo) lo = hn;
-                }
-            if (lo < 20) lo = 20;
-            for (int y = lo; y < h; ++y) {
-                const int kind = (y == h - 1) ? 0 : (y >= h - 3 ? 1 : 5);  // grass top, dirt, then stone
-                octree_insert(w->root, VoxelObjCreate(voxels[kind], voxelColors[kind], iv3(x, y, z)));
+// BASELINE config 4: the reference's commented-out terrain generator (src/main.cpp:487-503) over a caller-supplied
+// height field -- the loop order (z outer, x inner, y ascending), the material tests in the reference's order (the
+// two lowest voxels of a column STONE, the top one DIRT, the rest GRASS; colours/materials of src/main.cpp:220-259),
+// with the column's lower end at max(floor_y, h - band) as SURVEY.md 8(d) scales it (the reference fills from 20 up).
+// heights: size_x * size_z uint16, row z, column x; columns x in [x0, x0 + nx), z in [z0, z0 + nz) are inserted at
+// world (x, y, z). The noise itself is data: tests/golden/terrain_heights.npz holds the field the reference's own
+// FastNoiseLite.h produces (oracle/ref_noise_driver.cpp).
+int vrth_world_fill_heights(vrth_world *w, const uint16_t *heights, int size_x, int size_z, int x0, int z0, int nx, int nz,
+                            int band, int floor_y) {
+    if (!w || !heights || size_x < 1 || size_z < 1 || band < 1 || x0 < 0 || z0 < 0 || nx < 0 || nz < 0 ||
+        x0 + nx > size_x || z0 + nz > size_z)
+        return -1;
+    for (int z = z0; z < z0 + nz; ++z)
+        for (int x = x0; x < x0 + nx; ++x) {
+            const int height = heights[(size_t)z * (size_t)size_x + (size_t)x];
+            const int lo = height - band > floor_y ? height - band : floor_y;
+            for (int h = lo; h < height; ++h) {
+                const int kind = (h == lo || h == lo + 1) ? 5 : (h == height - 1 ? 1 : 0);  // VOX_STONE, VOX_DIRT, VOX_GRASS
+                octree_insert(w->root, VoxelObjCreate(voxels[kind], voxelColors[kind], iv3(x, h, z)));
             }
         }
     return 0;

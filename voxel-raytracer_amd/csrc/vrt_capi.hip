@@ -14,6 +14,7 @@
 #include "vrt_kernels.hip.h"
 #include "vrt_kernels_v1.hip.h"
 #include "vrt_kernels_wide.hip.h"
+#include "vrt_kernels_v4.hip.h"
 #include "vrt_full.hip.h"
 #include "vrt_denoise.hip.h"
 #include "vrt_layout.h"
@@ -56,6 +57,10 @@ const Variant kVariants[] = {
     /*18*/ {3, false, 16, 256, 0, 0, 1},
     /*19*/ {3, false, 8, 64, 0, 0, 7},
     /*20*/ {3, false, 8, 64, 0, 0, 6},  // variant 0 without its per-mode choice of waves per SIMD
+    /*21*/ {4, false, 8, 64, 0, 0, 6},  // v4: the wide lookup with the cost-aware march loop (vrt_kernels_v4.hip.h)
+    /*22*/ {4, false, 8, 64, 0, 0, 7},
+    /*23*/ {4, false, 8, 64, 0, 0, 8},
+    /*24*/ {4, false, 8, 64, 0, 0, 1},
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -178,6 +183,7 @@ hipError_t launch_mode(const Variant &v, const vrt::KArgs &a, const vrt::ViewSet
     using V2 = vrt::v2::Trav<false>;
     using V2L = vrt::v2::Trav<true>;
     using V3 = vrt::v3::Trav;
+    using V4 = vrt::v4::Trav;
     if (v.blocks_per_cu > 0) {  // the persistent (grid-stride) form exists for one combination
         if (v.trav == 2 && !v.use_lds && v.tw == 8 && v.block == 256 && v.wpe == 1)
             return launch_one<MODE, V2, 8, 256, 1, true>(a, vs, grid, lds, s, ev0, ev1);
@@ -205,6 +211,10 @@ hipError_t launch_mode(const Variant &v, const vrt::KArgs &a, const vrt::ViewSet
         case 3000000 + 8000 + 10 + 1: return launch_one<MODE, V3, 8, 64, 1>(a, vs, grid, lds, s, ev0, ev1);
         case 3000000 + 8000 + 10 + 8: return launch_one<MODE, V3, 8, 64, 8>(a, vs, grid, lds, s, ev0, ev1);
         case 3000000 + 16000 + 40 + 1: return launch_one<MODE, V3, 16, 256, 1>(a, vs, grid, lds, s, ev0, ev1);
+        case 4000000 + 8000 + 10 + 6: return launch_sched<MODE, V4, 8, 64, 6>(a, vs, grid, lds, s, ev0, ev1);
+        case 4000000 + 8000 + 10 + 7: return launch_sched<MODE, V4, 8, 64, 7>(a, vs, grid, lds, s, ev0, ev1);
+        case 4000000 + 8000 + 10 + 8: return launch_sched<MODE, V4, 8, 64, 8>(a, vs, grid, lds, s, ev0, ev1);
+        case 4000000 + 8000 + 10 + 1: return launch_sched<MODE, V4, 8, 64, 1>(a, vs, grid, lds, s, ev0, ev1);
         default: return hipErrorInvalidValue;
     }
 }
@@ -304,7 +314,7 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
         if (ra) return ra;
     }
     Variant v = kVariants[c->variant];
-    if (v.trav == 3 && !c->wide_ok) {  // wide layout not expressible for this scene: record-array kernels
+    if (v.trav >= 3 && !c->wide_ok) {  // wide layout not expressible for this scene: record-array kernels
         v.trav = 2; v.use_lds = false; v.tw = 8; v.block = 256; v.wpe = 1; v.lds_cap = 0;
     }
     if (v.trav == 2 && c->unit_internal) {  // precondition of vrt_kernels.hip.h not met: explicit-AABB kernels
@@ -316,7 +326,7 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
         // and no extra spills measured 8-10 % faster than the unconstrained 105-VGPR build) and, as baselines, for
         // the other two in one shape each
         v.use_lds = false; v.tw = 8; v.lds_cap = 0; v.blocks_per_cu = 0;
-        if (v.trav == 3) { v.block = v.block == 64 ? 64 : 256; v.wpe = 5; }
+        if (v.trav >= 3) { v.block = v.block == 64 ? 64 : 256; v.wpe = 5; }
         else { v.block = 256; v.wpe = 1; }
     } else if (mode == VRT_MODE_PRIMARY_SHADOW && c->variant == 0 && v.trav == 3) {
         v.wpe = 7;  // the default kernel with the shadow march is 1.5 % faster seven waves deep, the primary one six deep
@@ -394,8 +404,8 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     // feedback scheduling: wide-traversal kernels, one view, launches large enough to have a tail worth shaping
     SchedState *st = nullptr;
     bool measure = false;
-    const bool sched_kernel = v.trav == 3 && !v.use_lds && v.tw == 8 && v.blocks_per_cu == 0 && n_views == 1 &&
-                              ((v.block == 64 && (v.wpe == 5 || v.wpe == 6 || v.wpe == 7)) ||
+    const bool sched_kernel = v.trav >= 3 && !v.use_lds && v.tw == 8 && v.blocks_per_cu == 0 && n_views == 1 &&
+                              (v.trav == 4 || (v.block == 64 && (v.wpe == 5 || v.wpe == 6 || v.wpe == 7)) ||
                                (v.block == 256 && (v.wpe == 5 || v.wpe == 6)));
     const long groups = (tiles + vrt::kGroupTiles - 1) / vrt::kGroupTiles;
     if (sched_kernel && c->dbg_sched) {
@@ -419,7 +429,8 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     const hipEvent_t ev1 = prof ? c->prof_events[2 * c->prof_count + 1] : nullptr;
     hipError_t e;
     if (mode == VRT_MODE_FULL) {
-        if (v.trav == 3 && v.block == 64) e = launch_sched<2, vrt::v3::Trav, 8, 64, 5>(a, vs, (int)grid, 0, s, ev0, ev1);
+        if (v.trav == 4) e = launch_sched<2, vrt::v4::Trav, 8, 64, 5>(a, vs, (int)grid, 0, s, ev0, ev1);
+        else if (v.trav == 3 && v.block == 64) e = launch_sched<2, vrt::v3::Trav, 8, 64, 5>(a, vs, (int)grid, 0, s, ev0, ev1);
         else if (v.trav == 3) e = launch_sched<2, vrt::v3::Trav, 8, 256, 5>(a, vs, (int)grid, 0, s, ev0, ev1);
         else if (v.trav == 2) e = launch_one<2, vrt::v2::Trav<false>, 8, 256, 1>(a, vs, (int)grid, 0, s);
         else e = launch_one<2, vrt::v1::Trav<false>, 8, 256, 1>(a, vs, (int)grid, 0, s);
