@@ -34,7 +34,7 @@ POSES = {  # framing poses of SURVEY.md 8(d): x, y, z, yaw, pitch
 }
 GOLDEN_KEY = {"dragon": "dragon_1080p", "monu9": "monu9_720p", "nature": "nature_4k", "terrain": "terrain_1080p"}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-KERNEL_SAMPLES = 16    # launches of the timed region that carry a hipEvent pair (every max(1, steps // 16)-th)
+KERNEL_SAMPLES = 16    # launches of the timed region that carry a hipEvent pair (every max(2, steps // 16)-th: >= 10 of 20)
 
 
 def metric_name():
@@ -301,7 +301,7 @@ def main():
         fence()
         # a hipEvent pair rides on every n-th launch of the timed region (a pair on EVERY launch of a long run keeps
         # consecutive launches from overlapping and costs a few percent of the frame rate)
-        every = max(1, args.steps // KERNEL_SAMPLES)
+        every = max(2, args.steps // KERNEL_SAMPLES) if args.steps >= 4 else 1
         ctx.set_profiling(args.steps if profile else 0, every=every)
         t0 = time.perf_counter()
         for _ in range(args.steps):

@@ -186,8 +186,11 @@ int vrt_synchronize(vrt_ctx *ctx);
 void *vrt_stream(vrt_ctx *ctx);
 int vrt_device(const vrt_ctx *ctx);
 
-/* kernel variant selection for A/B measurement (0 = default) */
+/* kernel variant selection (0 = default). The shipped library holds the default and the fallbacks its dispatcher may
+ * take (variants 0, 1, 4, 20, 22); the A/B variants exist only in a `make AB=1` build: vrt_variant_available() says
+ * which, vrt_set_variant() returns VRT_E_INVALID for the others. */
 int vrt_set_variant(vrt_ctx *ctx, int variant);
+int vrt_variant_available(int variant);
 
 /* Feedback scheduling of the tracing kernel and the display pass (on by default, period 16). Frames that repeat a
  * launch shape on a stream -- the reference's loop dispatches the same W x H every frame (main.cpp:946) -- start

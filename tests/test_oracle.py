@@ -42,7 +42,14 @@ def test_small_frames_match_committed_hashes(O, golden):
         if g["width"] * g["height"] > 64 * 1024:
             continue
         if g["map"] not in scenes:
-            tree, _, _ = O.load_vox(os.path.join(MAPS, g["map"] + ".vox"))
+            if g["map"] == "terrain":   # BASELINE config 4: the height-field fixture (tests/golden/make_terrain.py)
+                t = golden["terrain"]
+                tree, wd = O.new_tree(), t["window"]
+                O.fill_heights(tree, np.load(os.path.join(os.path.dirname(MAPS), "terrain_heights.npz"))["heights"],
+                               wd["x0"], wd["z0"], wd["nx"], wd["nz"], t["band"], t["floor"])
+            else:
+                tree, ok, _ = O.load_vox(os.path.join(MAPS, g["map"] + ".vox"))
+                assert ok, g["map"]
             scenes[g["map"]] = O.flatten(tree)
         tex, dim = scenes[g["map"]]
         p = g["pose"]

@@ -7,7 +7,9 @@
 For every basic block of the kernel: instructions by class and the SIMD time they cost when the SIMD is saturated
 (tools/micro/valu_rate: ticks per instruction per SIMD at w resident waves). The traversal kernels are issue bound, so the
 sum over a loop body, weighted by trip counts, is the time a DDA step costs; use it to compare two builds of a loop
-without a GPU. Unknown mnemonics are priced by encoding class (VOP3 integer 2.9, other VALU 1.65, SALU 2.7).
+without a GPU. Unknown mnemonics are priced by encoding class (VOP3 integer 4.4, other VALU 2.6).
+Vector and scalar instructions issue from different ports (a v_add_f32 + s_add_u32 pair costs what the slower of the two
+does), so the totals are printed per port; the vector port is the one that binds these kernels.
 """
 import argparse
 import collections
@@ -51,7 +53,8 @@ SUFFIX = re.compile(r"_(e32|e64|sdwa|dpp)$")
 
 def load_table(path, w):
     t = json.load(open(path))
-    return {k: v[w]["simd"] for k, v in t.items()}
+    return {k: v[w].get("wall", v[w]["simd"]) for k, v in t.items()}   # by the launch wall time: the per-wave stamps
+    # over-state the rate once the probe's own registers keep fewer than w waves resident
 
 
 def price(mn, table):
@@ -70,10 +73,10 @@ def price(mn, table):
         return 4.0, "mem"   # issue slot only; the TA / LDS time is not an issue cost
     if base in MAP and MAP[base] in table:
         c = table[MAP[base]]
-        cls = "valu-fast" if c < 1.1 else ("valu-mid" if c < 2.0 else "valu-slow")
+        cls = "valu-full" if c < 3.2 else ("valu-half" if c < 6.0 else "valu-quarter")
         return c, cls
     if base.startswith("v_"):
-        return (2.9, "valu-slow?") if mn.endswith("_e64") or re.search(r"3_|_or_|_add_|lshl", base) else (1.65, "valu-mid?")
+        return (4.4, "valu-half?") if mn.endswith("_e64") or re.search(r"3_|_or_|_add_|lshl", base) else (2.6, "valu-full?")
     return 0.0, "other"
 
 
@@ -82,7 +85,7 @@ def main():
     ap.add_argument("asm")
     ap.add_argument("kernel")
     ap.add_argument("--table", default=os.path.join(ROOT, "profiles", "r02_valu_rate.json"))
-    ap.add_argument("--w", default="w6")
+    ap.add_argument("--w", default="w8")
     ap.add_argument("--blocks", action="store_true", help="per basic block lines")
     ap.add_argument("--top", type=int, default=0, help="the N most expensive mnemonics of the whole kernel")
     a = ap.parse_args()
@@ -116,10 +119,11 @@ def main():
     grand = 0.0
     for name, line_no, ins in blocks:
         c = sum(x[1] for x in ins)
+        cv = sum(x[1] for x in ins if x[2].startswith(("valu", "v_cmp")))
         grand += c
         if a.blocks and ins:
             by = collections.Counter(x[2].rstrip("?") for x in ins)
-            print(f"{name:<60s} L{line_no - start:<5d} n={len(ins):3d} cost={c:7.1f}  " + " ".join(f"{k}:{v}" for k, v in sorted(by.items())))
+            print(f"{name:<60s} L{line_no - start:<5d} n={len(ins):3d} vector={cv:6.1f} other={c - cv:6.1f}  " + " ".join(f"{k}:{v}" for k, v in sorted(by.items())))
     n = sum(total.values())
     print(f"kernel total: {n} instructions, static SIMD cost {grand:.0f} ticks ({grand / max(n, 1):.2f} per instruction at {a.w}); by class: "
           + ", ".join(f"{k} {v}" for k, v in sorted(total.items())))

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void probe(float *out, uint64_t *stamps, float
     }
 }
 
-struct Result { double wave, simd, ghz; };
+struct Result { double wave, simd, ghz, wall; };  // wall: launch time (hipEvents) x in-kernel clock / (instructions per wave x w): SIMD ticks per instruction by the wall clock
 
 template <int KIND>
 static Result run(int cus, int w, float *d_out, uint64_t *d_st) {
@@ -182,8 +182,18 @@ static Result run(int cus, int w, float *d_out, uint64_t *d_st) {
     lds -= lds % 1024;
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&probe<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(probe<KIND>, dim3(blocks), dim3(256), lds, 0, d_out, d_st, 1.0f, 1, 3u);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(probe<KIND>, dim3(blocks), dim3(256), lds, 0, d_out, d_st, 1.0f, 1, 3u);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(probe<KIND>, dim3(blocks), dim3(256), lds, 0, d_out, d_st, 1.0f, 1, 3u);
+    hipEventRecord(e1, 0);
     hipDeviceSynchronize();
+    float ms = 0.0f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
     std::vector<uint64_t> st((size_t)blocks * 4 * 2);
     hipMemcpy(st.data(), d_st, st.size() * sizeof(uint64_t), hipMemcpyDeviceToHost);
     std::vector<double> ticks, ghz;
@@ -195,7 +205,8 @@ static Result run(int cus, int w, float *d_out, uint64_t *d_st) {
     std::sort(ghz.begin(), ghz.end());
     const double n = (double)kIters * kUnroll * kInstsPer[KIND];
     const double wave = ticks[ticks.size() / 2] / n;
-    return Result{wave, wave / w, ghz.empty() ? 0.0 : ghz[ghz.size() / 2]};
+    const double g = ghz.empty() ? 0.0 : ghz[ghz.size() / 2];
+    return Result{wave, wave / w, g, (double)ms * 1e-3 * g * 1e9 / (n * w)};
 }
 
 template <int KIND>
@@ -205,9 +216,9 @@ static void sweep(int cus, float *d_out, uint64_t *d_st, std::string &json) {
     json += std::string(json.size() > 1 ? ",\n" : "\n") + "  \"" + kNames[KIND] + "\": {";
     for (int k = 0; k < 5; ++k) {
         const Result r = run<KIND>(cus, ws[k], d_out, d_st);
-        printf("  w%d %6.2f/%5.2f", ws[k], r.wave, r.simd);
+        printf("  w%d %6.2f/%5.2f/%5.2f", ws[k], r.wave, r.simd, r.wall);
         char buf[128];
-        snprintf(buf, sizeof buf, "%s\"w%d\": {\"wave\": %.3f, \"simd\": %.3f, \"ghz\": %.3f}", k ? ", " : "", ws[k], r.wave, r.simd, r.ghz);
+        snprintf(buf, sizeof buf, "%s\"w%d\": {\"wave\": %.3f, \"simd\": %.3f, \"ghz\": %.3f, \"wall\": %.3f}", k ? ", " : "", ws[k], r.wave, r.simd, r.ghz, r.wall);
         json += buf;
     }
     json += "}";

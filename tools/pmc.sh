@@ -15,6 +15,8 @@ PASSES=(
  "WRITE_SIZE"
  "GRBM_GUI_ACTIVE GRBM_COUNT"
  "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES"
+ "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_IFETCH SQ_INST_LEVEL_VMEM SQ_WAIT_INST_LDS SQ_INSTS_SENDMSG SQ_ACTIVE_INST_FLAT"
+ "SQ_INSTS_WAVE32 SQ_WAVES_RESTORED SQ_WAVE_READY SQ_WAVE_DEP_WAIT SQ_WAVE_ISSUE_WAIT SQ_WAVE_SCHED_WAIT SQ_IFETCH_LEVEL SQ_ACCUM_PREV"
 )
 i=0
 for p in "${PASSES[@]}"; do

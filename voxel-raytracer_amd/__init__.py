@@ -145,12 +145,19 @@ def hip_lib():
         L.vrt_stream.argtypes = [C.c_void_p]
         L.vrt_device.argtypes = [C.c_void_p]
         L.vrt_set_variant.argtypes = [C.c_void_p, C.c_int]
+        L.vrt_variant_available.argtypes = [C.c_int]
         L.vrt_version.restype = C.c_char_p
         L.vrt_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.vrt_debug_build_layout.restype = C.c_long
         L.vrt_debug_build_layout.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(SceneInfo)]
         _hip = L
     return _hip
+
+
+def available_variants(upto=64):
+    """kernel variants compiled into libvrt_hip.so (the shipped ones; all of them in a `make AB=1` build)"""
+    L = hip_lib()
+    return [v for v in range(upto) if L.vrt_variant_available(v)]
 
 
 def _fptr(a):

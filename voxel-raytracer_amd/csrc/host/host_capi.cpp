@@ -331,7 +331,7 @@ int vrth_make_custom_vox(uint8_t **out, size_t *out_len) {
 // with the column's lower end at max(floor_y, h - band) as SURVEY.md 8(d) scales it (the reference fills from 20 up).
 // heights: size_x * size_z uint16, row z, column x; columns x in [x0, x0 + nx), z in [z0, z0 + nz) are inserted at
 // world (x, y, z). The noise itself is data: tests/golden/terrain_heights.npz holds the field the reference's own
-// FastNoiseLite.h produces (oracle/ref_noise_driver.cpp).
+// FastNoiseLite.h produces (generated by tests/golden/make_terrain.py).
 int vrth_world_fill_heights(vrth_world *w, const uint16_t *heights, int size_x, int size_z, int x0, int z0, int nx, int nz,
                             int band, int floor_y) {
     if (!w || !heights || size_x < 1 || size_z < 1 || band < 1 || x0 < 0 || z0 < 0 || nx < 0 || nz < 0 ||

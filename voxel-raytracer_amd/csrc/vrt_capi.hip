@@ -33,10 +33,17 @@ struct Variant {
     int wpe;           // waves per SIMD the register allocator is held to (1 = unconstrained)
 };
 
-// variant 0 is the default the library ships with; the others exist for A/B measurement
-// (see launch_mode() for the combinations that are instantiated)
+// Variant 0 is what the library ships: the v4 traversal, seven waves per SIMD; the dispatcher takes v3 when the eye is
+// inside a medium and for the full path tracer, v2 when the scene has no wide form, v1 when it has a unit-size internal
+// node. Variants 1, 4 and 20 select those fallbacks explicitly (tests). Everything else is A/B material and is only
+// compiled into the library with `make AB=1` (-DVRT_AB_VARIANTS); vrt_set_variant() refuses what is not there.
+#ifdef VRT_AB_VARIANTS
+#define VRT_AB 1
+#else
+#define VRT_AB 0
+#endif
 const Variant kVariants[] = {
-    /*0*/ {3, false, 8, 64, 0, 0, 6},
+    /*0*/ {4, false, 8, 64, 0, 0, 7},
     /*1*/ {1, false, 8, 256, 0, 0, 1},
     /*2*/ {2, true, 8, 256, 2048, 0, 1},
     /*3*/ {2, false, 16, 256, 0, 0, 1},
@@ -56,13 +63,16 @@ const Variant kVariants[] = {
     /*17*/ {3, false, 8, 64, 0, 0, 8},
     /*18*/ {3, false, 16, 256, 0, 0, 1},
     /*19*/ {3, false, 8, 64, 0, 0, 7},
-    /*20*/ {3, false, 8, 64, 0, 0, 6},  // variant 0 without its per-mode choice of waves per SIMD
-    /*21*/ {4, false, 8, 64, 0, 0, 6},  // v4: the wide lookup with the cost-aware march loop (vrt_kernels_v4.hip.h)
-    /*22*/ {4, false, 8, 64, 0, 0, 7},
+    /*20*/ {3, false, 8, 64, 0, 0, 6},  // v3 as round 1 shipped it (six waves per SIMD; seven with the shadow march)
+    /*21*/ {4, false, 8, 64, 0, 0, 6},
+    /*22*/ {4, false, 8, 64, 0, 0, 7},  // == variant 0
     /*23*/ {4, false, 8, 64, 0, 0, 8},
     /*24*/ {4, false, 8, 64, 0, 0, 1},
 };
+constexpr bool kVariantShipped[] = {true, true, false, false, true, false, false, false, false, false, false, false, false,
+                                    false, false, false, false, false, false, false, true, false, true, false, false};
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
+static_assert(sizeof(kVariantShipped) / sizeof(kVariantShipped[0]) == (size_t)kNumVariants, "one flag per variant");
 
 }  // namespace
 
@@ -116,7 +126,7 @@ struct vrt_ctx {
     // wide layout (vrt_layout.h), rebuilt whenever the tree or the world bounds change
     bool wide_ok = false;
     vrt::WideTree wide;
-    uint2 *d_cells = nullptr;
+    uint2 *d_cells = nullptr;     // cells_capacity cells in the layout of vrt_layout.h, then as many in the v4 form (cells4)
     uint32_t *d_roots = nullptr;  // 16 words: record and wide node of each wide root (vrt_common.hip.h KArgs::root_table)
     size_t cells_capacity = 0;
     // feedback scheduling of the default kernel (see SchedState)
@@ -179,21 +189,30 @@ template <int MODE>
 hipError_t launch_mode(const Variant &v, const vrt::KArgs &a, const vrt::ViewSet &vs, int grid, size_t lds, hipStream_t s,
                        hipEvent_t ev0, hipEvent_t ev1) {
     using V1 = vrt::v1::Trav<false>;
-    using V1L = vrt::v1::Trav<true>;
     using V2 = vrt::v2::Trav<false>;
+#if VRT_AB
+    using V1L = vrt::v1::Trav<true>;
     using V2L = vrt::v2::Trav<true>;
+#endif
     using V3 = vrt::v3::Trav;
     using V4 = vrt::v4::Trav;
+#if VRT_AB
     if (v.blocks_per_cu > 0) {  // the persistent (grid-stride) form exists for one combination
         if (v.trav == 2 && !v.use_lds && v.tw == 8 && v.block == 256 && v.wpe == 1)
             return launch_one<MODE, V2, 8, 256, 1, true>(a, vs, grid, lds, s, ev0, ev1);
         return hipErrorInvalidValue;
     }
+#endif
     const int key = v.trav * 1000000 + (v.use_lds ? 100000 : 0) + v.tw * 1000 + (v.block / 64) * 10 + v.wpe;
     switch (key) {
-        case 1000000 + 8000 + 40 + 1: return launch_one<MODE, V1, 8, 256, 1>(a, vs, grid, lds, s, ev0, ev1);
-        case 1100000 + 8000 + 40 + 1: return launch_one<MODE, V1L, 8, 256, 1>(a, vs, grid, lds, s, ev0, ev1);
+        // shipped: the default (v4) and the three fallbacks the dispatcher may take
+        case 4000000 + 8000 + 10 + 7: return launch_sched<MODE, V4, 8, 64, 7>(a, vs, grid, lds, s, ev0, ev1);
+        case 3000000 + 8000 + 10 + 6: return launch_sched<MODE, V3, 8, 64, 6>(a, vs, grid, lds, s, ev0, ev1);
+        case 3000000 + 8000 + 10 + 7: return launch_sched<MODE, V3, 8, 64, 7>(a, vs, grid, lds, s, ev0, ev1);
         case 2000000 + 8000 + 40 + 1: return launch_one<MODE, V2, 8, 256, 1>(a, vs, grid, lds, s, ev0, ev1);
+        case 1000000 + 8000 + 40 + 1: return launch_one<MODE, V1, 8, 256, 1>(a, vs, grid, lds, s, ev0, ev1);
+#if VRT_AB
+        case 1100000 + 8000 + 40 + 1: return launch_one<MODE, V1L, 8, 256, 1>(a, vs, grid, lds, s, ev0, ev1);
         case 2000000 + 8000 + 40 + 5: return launch_one<MODE, V2, 8, 256, 5>(a, vs, grid, lds, s, ev0, ev1);
         case 2000000 + 8000 + 40 + 6: return launch_one<MODE, V2, 8, 256, 6>(a, vs, grid, lds, s, ev0, ev1);
         case 2000000 + 8000 + 40 + 8: return launch_one<MODE, V2, 8, 256, 8>(a, vs, grid, lds, s, ev0, ev1);
@@ -206,15 +225,13 @@ hipError_t launch_mode(const Variant &v, const vrt::KArgs &a, const vrt::ViewSet
         case 3000000 + 8000 + 40 + 1: return launch_one<MODE, V3, 8, 256, 1>(a, vs, grid, lds, s, ev0, ev1);
         case 3000000 + 8000 + 40 + 6: return launch_sched<MODE, V3, 8, 256, 6>(a, vs, grid, lds, s, ev0, ev1);
         case 3000000 + 8000 + 40 + 8: return launch_one<MODE, V3, 8, 256, 8>(a, vs, grid, lds, s, ev0, ev1);
-        case 3000000 + 8000 + 10 + 6: return launch_sched<MODE, V3, 8, 64, 6>(a, vs, grid, lds, s, ev0, ev1);
-        case 3000000 + 8000 + 10 + 7: return launch_sched<MODE, V3, 8, 64, 7>(a, vs, grid, lds, s, ev0, ev1);
         case 3000000 + 8000 + 10 + 1: return launch_one<MODE, V3, 8, 64, 1>(a, vs, grid, lds, s, ev0, ev1);
         case 3000000 + 8000 + 10 + 8: return launch_one<MODE, V3, 8, 64, 8>(a, vs, grid, lds, s, ev0, ev1);
         case 3000000 + 16000 + 40 + 1: return launch_one<MODE, V3, 16, 256, 1>(a, vs, grid, lds, s, ev0, ev1);
         case 4000000 + 8000 + 10 + 6: return launch_sched<MODE, V4, 8, 64, 6>(a, vs, grid, lds, s, ev0, ev1);
-        case 4000000 + 8000 + 10 + 7: return launch_sched<MODE, V4, 8, 64, 7>(a, vs, grid, lds, s, ev0, ev1);
         case 4000000 + 8000 + 10 + 8: return launch_sched<MODE, V4, 8, 64, 8>(a, vs, grid, lds, s, ev0, ev1);
         case 4000000 + 8000 + 10 + 1: return launch_sched<MODE, V4, 8, 64, 1>(a, vs, grid, lds, s, ev0, ev1);
+#endif
         default: return hipErrorInvalidValue;
     }
 }
@@ -326,10 +343,13 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
         // and no extra spills measured 8-10 % faster than the unconstrained 105-VGPR build) and, as baselines, for
         // the other two in one shape each
         v.use_lds = false; v.tw = 8; v.lds_cap = 0; v.blocks_per_cu = 0;
-        if (v.trav >= 3) { v.block = v.block == 64 ? 64 : 256; v.wpe = 5; }
+        // the default takes the v3 traversal here: with the v4 loops the full path tracer's 96-register build spills and
+        // measured 10 % slower (profiles/r02_variant_sweep.jsonl); variants 21-24 select it explicitly in an A/B build
+        if (v.trav == 4 && (c->variant == 0 || !VRT_AB)) v.trav = 3;
+        if (v.trav >= 3) { v.block = (v.block == 64 || !VRT_AB) ? 64 : 256; v.wpe = 5; }
         else { v.block = 256; v.wpe = 1; }
-    } else if (mode == VRT_MODE_PRIMARY_SHADOW && c->variant == 0 && v.trav == 3) {
-        v.wpe = 7;  // the default kernel with the shadow march is 1.5 % faster seven waves deep, the primary one six deep
+    } else if (mode == VRT_MODE_PRIMARY_SHADOW && c->variant == 20 && v.trav == 3) {
+        v.wpe = 7;  // round 1's default: the shadow march was 1.5 % faster seven waves deep, the primary one six deep
     }
     vrt::KArgs a;
     vrt::ViewSet vs;
@@ -357,6 +377,16 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
             w.first_s = ff.s; w.first_as = ff.as;
         }
     }
+    if (v.trav == 4 && mode != VRT_MODE_FULL) {
+        // the v4 primary kernels hold the march loop for rays that start in refraction byte 85 (1.0) only: an eye inside a
+        // medium (comp:445-449: refraction byte 1..254 of the voxel that holds it) takes the v3 kernels
+        bool eye_in_medium = false;
+        for (int i = 0; i < n_views; ++i) {
+            const uint32_t b = vs.v[i].eye1 & 0xffu;
+            eye_in_medium = eye_in_medium || (b >= 1u && b <= 254u && b != 85u);
+        }
+        if (eye_in_medium) { v.trav = 3; v.wpe = 6; }
+    }
     a.voxel_scale = c->params.voxel_scale;
     for (int i = 0; i < 3; ++i) {
         a.wmin[i] = c->params.world_min[i];
@@ -377,6 +407,7 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     a.n_records = c->info.n_records;
     a.lds_records = v.use_lds ? (c->info.n_records < v.lds_cap ? c->info.n_records : v.lds_cap) : 0u;
     a.cells = c->d_cells;
+    a.cells4 = c->d_cells ? c->d_cells + c->cells_capacity : nullptr;
     a.n_roots = c->wide_ok ? (uint32_t)c->wide.roots.size() : 0u;
     for (int k = 0; k < 3; ++k) a.root0_min[k] = a.n_roots ? c->wide.roots[0].origin[k] : 0;
     a.root_table = c->d_roots;
@@ -429,9 +460,11 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     const hipEvent_t ev1 = prof ? c->prof_events[2 * c->prof_count + 1] : nullptr;
     hipError_t e;
     if (mode == VRT_MODE_FULL) {
-        if (v.trav == 4) e = launch_sched<2, vrt::v4::Trav, 8, 64, 5>(a, vs, (int)grid, 0, s, ev0, ev1);
-        else if (v.trav == 3 && v.block == 64) e = launch_sched<2, vrt::v3::Trav, 8, 64, 5>(a, vs, (int)grid, 0, s, ev0, ev1);
+        if (v.trav == 3 && v.block == 64) e = launch_sched<2, vrt::v3::Trav, 8, 64, 5>(a, vs, (int)grid, 0, s, ev0, ev1);
+#if VRT_AB
+        else if (v.trav == 4) e = launch_sched<2, vrt::v4::TravAny, 8, 64, 5>(a, vs, (int)grid, 0, s, ev0, ev1);
         else if (v.trav == 3) e = launch_sched<2, vrt::v3::Trav, 8, 256, 5>(a, vs, (int)grid, 0, s, ev0, ev1);
+#endif
         else if (v.trav == 2) e = launch_one<2, vrt::v2::Trav<false>, 8, 256, 1>(a, vs, (int)grid, 0, s);
         else e = launch_one<2, vrt::v1::Trav<false>, 8, 256, 1>(a, vs, (int)grid, 0, s);
     } else {
@@ -654,6 +687,29 @@ namespace {
 // (re)derives what depends on the world bounds: whether the wide layout can be used, and the layout itself on the
 // device. Called lazily by the dispatcher and by the patch entry points.
 // the wide roots' table on the device; blocking (callers have synchronised the device or run before any dispatch)
+// The wide cells live on the device twice: as vrt_layout.h lays them out (v3 kernels, tests) and in the form the v4
+// kernels read (vrt::to_cell4), behind it in the same allocation. cells_capacity counts CELLS of one form.
+int reserve_cells(vrt_ctx *c, size_t n_cells) {
+    if (n_cells <= c->cells_capacity) return VRT_OK;
+    uint2 *fresh = nullptr;
+    VRT_HIP(c, hipMalloc((void **)&fresh, 2 * n_cells * sizeof(uint2)));   // before the old one goes: a failure leaves the context usable
+    if (c->d_cells) (void)hipFree(c->d_cells);
+    c->d_cells = fresh;
+    c->cells_capacity = n_cells;
+    return VRT_OK;
+}
+
+// cells [from, from + n) of c->wide to the device in both forms; blocking (callers have synchronised the device)
+int upload_cells(vrt_ctx *c, size_t from, size_t n) {
+    if (n == 0) return VRT_OK;
+    if (from + n > c->wide.cells.size() || from + n > c->cells_capacity) return fail(c, VRT_E_STATE, "upload_cells: range outside the wide layout");
+    VRT_HIP(c, hipMemcpy(c->d_cells + from, c->wide.cells.data() + from, n * sizeof(vrt::WideCell), hipMemcpyHostToDevice));
+    std::vector<vrt::WideCell> c4(n);
+    for (size_t i = 0; i < n; ++i) c4[i] = vrt::to_cell4(c->wide.cells[from + i]);
+    VRT_HIP(c, hipMemcpy(c->d_cells + c->cells_capacity + from, c4.data(), n * sizeof(vrt::WideCell), hipMemcpyHostToDevice));
+    return VRT_OK;
+}
+
 int upload_roots(vrt_ctx *c) {
     uint32_t t[16];
     for (int i = 0; i < 8; ++i) {
@@ -673,19 +729,15 @@ int ensure_analysis(vrt_ctx *c) {
     c->wide_ok = !c->unit_internal &&
                  vrt::build_wide(c->host_records, c->params.world_min, c->params.world_max, c->wide, why);
     if (c->wide_ok) {
-        const size_t bytes = (c->wide.cells.empty() ? 64 : c->wide.cells.size()) * sizeof(vrt::WideCell);
-        if (bytes > c->cells_capacity) {
-            VRT_HIP(c, hipDeviceSynchronize());
-            if (c->d_cells) VRT_HIP(c, hipFree(c->d_cells));
-            c->d_cells = nullptr;
-            c->cells_capacity = 0;
-            VRT_HIP(c, hipMalloc((void **)&c->d_cells, bytes + bytes / 2));  // room for patches
-            c->cells_capacity = bytes + bytes / 2;
-        }
-        // rare (scene or bounds changed): a blocking copy keeps it ordered against any caller stream
+        const size_t n_cells = c->wide.cells.empty() ? 64 : c->wide.cells.size();
+        // rare (scene or bounds changed): blocking copies keep it ordered against any caller stream
         VRT_HIP(c, hipDeviceSynchronize());
-        if (!c->wide.cells.empty())
-            VRT_HIP(c, hipMemcpy(c->d_cells, c->wide.cells.data(), c->wide.cells.size() * sizeof(vrt::WideCell), hipMemcpyHostToDevice));
+        if (n_cells > c->cells_capacity) {
+            const int rr = reserve_cells(c, n_cells + n_cells / 2);  // room for patches
+            if (rr) { c->have_scene = false; return rr; }
+        }
+        const int rr = upload_cells(c, 0, c->wide.cells.size());
+        if (rr) return rr;
     }
     VRT_HIP(c, hipDeviceSynchronize());
     {
@@ -771,27 +823,19 @@ int vrt_patch_apply(vrt_ctx *c, const vrt_patch *patch, const uint32_t *subtree_
         if (rg.wide_invalid) {
             c->analysis_valid = false;  // the next dispatch rebuilds the wide layout from the patched records
         } else {
-            const size_t cell_bytes = c->wide.cells.size() * sizeof(vrt::WideCell);
-            if (cell_bytes > c->cells_capacity) {
-                if (c->d_cells) VRT_HIP(c, hipFree(c->d_cells));
-                c->d_cells = nullptr;
-                c->cells_capacity = 0;
-                VRT_HIP(c, hipMalloc((void **)&c->d_cells, cell_bytes * 2));
-                c->cells_capacity = cell_bytes * 2;
-                VRT_HIP(c, hipMemcpy(c->d_cells, c->wide.cells.data(), cell_bytes, hipMemcpyHostToDevice));
+            int rr = VRT_OK;
+            if (c->wide.cells.size() > c->cells_capacity) {
+                rr = reserve_cells(c, c->wide.cells.size() * 2);
+                if (!rr) rr = upload_cells(c, 0, c->wide.cells.size());
             } else {
                 const size_t from = rg.cells_appended_from;
-                if (c->wide.cells.size() > from)
-                    VRT_HIP(c, hipMemcpy(c->d_cells + from, c->wide.cells.data() + from, (c->wide.cells.size() - from) * sizeof(vrt::WideCell),
-                                         hipMemcpyHostToDevice));
-                if (site.root_index >= 0) {
-                    const int rr = upload_roots(c);
-                    if (rr) return rr;
-                }
-                if (rg.cell_repointed) {
-                    const size_t at = (size_t)site.parent_node * 64 + site.parent_cell;
-                    VRT_HIP(c, hipMemcpy(c->d_cells + at, c->wide.cells.data() + at, sizeof(vrt::WideCell), hipMemcpyHostToDevice));
-                }
+                if (c->wide.cells.size() > from) rr = upload_cells(c, from, c->wide.cells.size() - from);
+                if (!rr && site.root_index >= 0) rr = upload_roots(c);
+                if (!rr && rg.cell_repointed) rr = upload_cells(c, (size_t)site.parent_node * 64 + site.parent_cell, 1);
+            }
+            if (rr) {   // the host structures are ahead of the device copies: force a full re-derivation before the next dispatch
+                c->analysis_valid = false;
+                return rr;
             }
         }
     }
@@ -821,9 +865,15 @@ int vrt_set_tile_scheduling(vrt_ctx *c, int period) {
     return VRT_OK;
 }
 
+int vrt_variant_available(int variant) {
+    return variant >= 0 && variant < kNumVariants && (VRT_AB || kVariantShipped[variant]) ? 1 : 0;
+}
+
 int vrt_set_variant(vrt_ctx *c, int variant) {
     if (!c) return VRT_E_INVALID;
     if (variant < 0 || variant >= kNumVariants) return fail(c, VRT_E_INVALID, "vrt_set_variant: unknown variant");
+    if (!VRT_AB && !kVariantShipped[variant])
+        return fail(c, VRT_E_INVALID, "vrt_set_variant: an A/B variant; this library was built without them (make AB=1)");
     c->variant = variant;
     return VRT_OK;
 }

@@ -68,6 +68,7 @@ struct KArgs {
     uint32_t lds_records;     // prefix of `nodes` staged in LDS by each workgroup
     // wide layout (vrt_layout.h): 64 cells per node; roots = octree records where a wide tree starts
     const uint2 *cells;
+    const uint2 *cells4;      // the same cells in the form of the v4 kernels (vrt_layout.h to_cell4)
     uint32_t n_roots;
     // wide roots: [0..7] octree record of each root, [8..15] its wide node (device memory; read only by the record
     // walk that a lookup outside wide root 0 takes). Root 0's node and log2 side also travel by value.

@@ -18,31 +18,53 @@
 //     anchor is inside the world by construction;
 //   * "no current node" is a walk state whose tests cannot pass (cell shift 0 and a `last` point no representable
 //     floor() can come within 4 of), not an extra flag;
-//   * planes, min-axis selection and the push in plain f32 / integer ops chosen from the table above.
+//   * planes, min-axis selection and the push in plain f32 / integer ops chosen from the table above: the cells are read
+//     in a second form (vrt_layout.h to_cell4) that carries 2^t as a float exponent, so a node's planes are
+//     (floor(floor(p) * 2^-t) + dpos) * 2^t in four f32 operations per axis -- every step exact, hence the same floats
+//     the integer arithmetic gives -- the child node as a byte offset, and the medium byte with 85 for empty space, so
+//     that "the medium changed" is one comparison;
+//   * the first cell load of a lookup is straight-line code, only a further descent loops; the walk's reference point
+//     moves only when the node changes.
 #pragma once
 #include "vrt_kernels_wide.hip.h"
 
 namespace vrt {
 namespace v4 {
 
-using v3::floor_i3_fast;
 using v3::in_world_u;
 using v3::kAnchorShift;
 
 struct Walk {                   // per-ray lookup state carried from one find to the next
-    uint32_t node, cs;          // current wide node and log2 of its CELL side (node side = 4 cells)
+    uint32_t node, cs;          // current wide node (BYTE offset in cells4) and log2 of its CELL side (node side = 4 cells)
     uint32_t anode, acs;        // anchor wide node (an ancestor of `node`, or `node` itself)
-    I3 last;                    // the previous query point (inside both)
+    I3 last;                    // a point inside `node` (hence inside the anchor)
 };
 
 struct Found {
-    uint32_t w0, w1;            // leaf words, or 0/0 for empty space
-    I3 plane;                   // per axis: the face of the node found that a ray with signs `dpos` leaves through
+    uint32_t x, y;              // the cell in to_cell4() form: leaf word 0; medium byte | illum << 8 | k ... (vrt_layout.h)
+    F3 plane;                   // per axis: the face of the node found that a ray with signs `dpos` leaves through
 };
 
 enum : int { kGo = 0, kDone = 1, kOutside = 2 };
+constexpr uint32_t kExpMask = 0x0f800000u;   // (t + 1) << 23; 0 in a subdivided cell
 
-struct Trav {
+// leaf word 1 as the other traversals report it: refr | illum << 8 | k << 16, refr 0 when alpha is 0
+VRT_DEV uint32_t word1_of(uint32_t x, uint32_t y) {
+    const uint32_t refr = ((x >> 24) == 0u || (y & (1u << 29)) != 0u) ? 0u : (y & 0xffu);
+    return refr | (y & 0x007fff00u) | ((y >> 5) & 0x00800000u);
+}
+// to_cell4() of a leaf given as (word 0, word 1 with refr 0 under alpha 0), t + 1 = tp1
+VRT_DEV uint32_t cell4_y(uint32_t w0, uint32_t w1, uint32_t tp1) {
+    const uint32_t b = w1 & 0xffu;
+    const uint32_t raw0 = (b == 0u && (w0 >> 24) != 0u) ? 1u : 0u;
+    return (b ? b : 85u) | (w1 & 0x007fff00u) | ((w1 & 0x00800000u) << 5) | (tp1 << 23) | (raw0 << 29);
+}
+
+// EYE85: the caller guarantees that every march() starts in refraction byte 85 (1.0) -- the primary rays of views whose
+// eye is in empty space, which the dispatcher checks (it has the eye's voxel) -- so the kernel holds one march loop and
+// its registers; otherwise march() chooses between the two loops per wave (the full path tracer's secondary rays).
+template <bool EYE85>
+struct TravT {
     static constexpr bool kStagesLds = false;
     using Ctx = v3::Trav::Ctx;
 
@@ -56,28 +78,38 @@ struct Trav {
         w.last = I3{0x55555555, 0x2aaaaaaa, 0x55555555};
     }
 
-    // octreeFind (comp:137-220): the deepest octree node containing p, through the wide layout.
-    // kGo: the answer came from a cell (f.w0, f.w1, f.plane set). kDone: from the record walk above the wide roots
-    // (f set). kOutside: p is outside the world (comp:143-145): f.w0 / f.w1 untouched, f.plane not set.
+    static VRT_DEV uint2 load_cell(const KArgs &a, uint32_t node, uint32_t cs, I3 p) {
+        const uint32_t bx = __builtin_amdgcn_ubfe((uint32_t)p.x, cs, 2u), by = __builtin_amdgcn_ubfe((uint32_t)p.y, cs, 2u),
+                       bz = __builtin_amdgcn_ubfe((uint32_t)p.z, cs, 2u);
+        const uint32_t off = ((((bx << 2) | by) << 2 | bz) << 3) | node;
+        return *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(a.cells4) + off);
+    }
+
+    // octreeFind (comp:137-220): the deepest octree node containing p (= floor of a ray position, pf the same as
+    // floats), through the wide layout.
+    // kGo: the answer came from a cell (f set). kDone: from the record walk above the wide roots (f set).
+    // kOutside: p is outside the world (comp:143-145): f untouched.
     //
     // A lookup that has left its anchor (or has none) takes the one conditional block of the march loop: world-bounds
     // test, then wide root 0 when the point lies in its cube -- where the descent from the octree root would arrive
     // anyway -- else the record walk of v3 (the other seven octants of the reference's world: a nested, rarely
     // entered block). Inside the block everything is a select, so its lanes meet again after a handful of instructions.
-    static VRT_DEV int find(const KArgs &a, const Ctx &c, I3 p, I3 dpos, Walk &w, Found &f) {
+    static VRT_DEV int find(const KArgs &a, const Ctx &c, I3 p, F3 pf, I3 dpos, F3 dposf, Walk &w, Found &f) {
         const uint32_t d = (uint32_t)((p.x ^ w.last.x) | (p.y ^ w.last.y) | (p.z ^ w.last.z));
         const bool in_node = (d >> w.cs) < 4u;
         const bool in_anchor = (d >> w.acs) < 4u;     // the anchor contains the node: in_node implies in_anchor
         uint32_t node = in_node ? w.node : w.anode;
         uint32_t cs = in_node ? w.cs : w.acs;
         uint32_t anode = w.anode, acs = w.acs;
+        I3 last = w.last;
         int status = kGo;
         if (!in_anchor) {
             const int rs = a.root0_shift;
             const uint32_t out0 = (uint32_t)((p.x ^ a.root0_min[0]) | (p.y ^ a.root0_min[1]) | (p.z ^ a.root0_min[2])) >> (rs & 31);
             const bool in0 = a.n_roots != 0u && out0 == 0u;
-            node = anode = a.root0_node;
+            node = anode = a.root0_node << 9;
             cs = acs = (uint32_t)(rs - 2);
+            last = p;
             status = in_world_u(a, p) ? (in0 ? kGo : kDone) : kOutside;
             asm volatile("" : "+v"(status));   // a vector register, not a pair of lane masks to merge
             if (status == kDone) {   // in the world, outside wide root 0: walk the records (v3)
@@ -87,54 +119,106 @@ struct Trav {
                 uint32_t n3 = 0u;
                 int s3 = 2;
                 if (v3::Trav::descend_generic(a, c, p, dpos, w3, f3, n3, s3)) {
-                    f.w0 = f3.w0; f.w1 = f3.w1; f.plane = f3.plane;
+                    f.x = f3.w0; f.y = cell4_y(f3.w0, f3.w1, 1u);
+                    f.plane = F3{(float)f3.plane.x, (float)f3.plane.y, (float)f3.plane.z};
                     node = anode = 0u; cs = acs = 0u;                  // reset(): no current node
-                    p = I3{0x55555555, 0x2aaaaaaa, 0x55555555};        // becomes w.last below
+                    last = I3{0x55555555, 0x2aaaaaaa, 0x55555555};
                 } else {
-                    node = anode = n3; cs = acs = (uint32_t)(s3 - 2);
+                    node = anode = n3 << 9; cs = acs = (uint32_t)(s3 - 2);
                     status = kGo;
                 }
             }
         }
-        uint2 cell = make_uint2(0u, 0u);
         if (status == kGo) {
-            for (;;) {
-                const uint32_t ci = (__builtin_amdgcn_ubfe((uint32_t)p.x, cs, 2u) << 4) |
-                                    (__builtin_amdgcn_ubfe((uint32_t)p.y, cs, 2u) << 2) |
-                                    __builtin_amdgcn_ubfe((uint32_t)p.z, cs, 2u);
-                cell = a.cells[(node << 6) | ci];
-                if ((int)cell.y >= 0) break;      // bit 31: subdivided further, cell.x = child wide node
-                node = cell.x;
-                const bool up = cs == (uint32_t)kAnchorShift;    // the child has side 2^kAnchorShift: the new anchor
-                cs -= 2u;
-                anode = up ? node : anode;
-                acs = up ? cs : acs;
+            uint2 cell = load_cell(a, node, cs, p);
+            uint32_t e = cell.y & kExpMask;
+            if (e == 0u) {            // subdivided further: cell.x = the child wide node
+                do {
+                    node = cell.x;
+                    const bool up = cs == (uint32_t)kAnchorShift;    // the child has side 2^kAnchorShift: the new anchor
+                    cs -= 2u;
+                    anode = up ? node : anode;
+                    acs = up ? cs : acs;
+                    cell = load_cell(a, node, cs, p);
+                    e = cell.y & kExpMask;
+                } while (e == 0u);
+                last = p;
             }
-            const int t = (int)(cell.y >> 24);  // log2 side of the octree node found
-            f.w0 = cell.x;
-            f.w1 = cell.y & 0x00ffffffu;
-            f.plane = I3{((p.x >> t) + dpos.x) << t, ((p.y >> t) + dpos.y) << t, ((p.z >> t) + dpos.z) << t};
+            f.x = cell.x; f.y = cell.y;
+            // the node found has side 2^t, t + 1 in the exponent field: its planes are ((p >> t) + dpos) << t
+            const float side = __uint_as_float(e + 0x3f000000u), inv_side = __uint_as_float(0x40000000u - e);
+            f.plane.x = (__builtin_floorf(pf.x * inv_side) + dposf.x) * side;
+            f.plane.y = (__builtin_floorf(pf.y * inv_side) + dposf.y) * side;
+            f.plane.z = (__builtin_floorf(pf.z * inv_side) + dposf.z) * side;
         }
-        w.node = node; w.cs = cs; w.anode = anode; w.acs = acs; w.last = p;
+        w.node = node; w.cs = cs; w.anode = anode; w.acs = acs; w.last = last;
         return status;
+    }
+
+    static VRT_DEV F3 world_planes(const KArgs &a, I3 dpos) {  // comp:143-145, convention C8: the world's bounds
+        return F3{(float)(dpos.x ? a.wmax[0] : a.wmin[0]), (float)(dpos.y ? a.wmax[1] : a.wmin[1]), (float)(dpos.z ? a.wmax[2] : a.wmin[2])};
     }
 
     // One DDA step (comp:278-307). The exit axis (comp:292): x when tx < ty && tx < tz, else y when ty < tz, else z;
     // with m = (ty < tz ? ty : tz) the first test is tx < m, and tStep = min(tx, min(ty, tz)) is the tMax of that axis.
-    static VRT_DEV int dda_step(F3 &rp, F3 dir, F3 inv, F3 push, I3 plane) {
-        const float tx = ((float)plane.x - rp.x) * inv.x;
-        const float ty = ((float)plane.y - rp.y) * inv.y;
-        const float tz = ((float)plane.z - rp.z) * inv.z;
+    // The vector port is what binds this kernel (a v_cndmask costs 4.4 ticks of it, a v_add_f32 2.6, scalar mask
+    // arithmetic none): the push (comp:300-304) is added under the axis' lane mask instead of being selected per axis.
+    struct Axis { bool x, yz; };   // exit axis: x ? 0 : (yz ? 1 : 2)
+    static VRT_DEV Axis dda_step(F3 &rp, F3 dir, F3 inv, F3 push, F3 plane) {
+        const float tx = (plane.x - rp.x) * inv.x;
+        const float ty = (plane.y - rp.y) * inv.y;
+        const float tz = (plane.z - rp.z) * inv.z;
         const bool yz = ty < tz;
         const float m = yz ? ty : tz;
         const bool ax = tx < m;
         const float t = ax ? tx : m;
-        const int axis = ax ? 0 : (yz ? 1 : 2);
-        const float rx = rp.x + dir.x * t, ry = rp.y + dir.y * t, rz = rp.z + dir.z * t;
-        rp.x = axis == 0 ? rx + push.x : rx;
-        rp.y = axis == 1 ? ry + push.y : ry;
-        rp.z = axis == 2 ? rz + push.z : rz;
-        return axis;
+        float rx = rp.x + dir.x * t, ry = rp.y + dir.y * t, rz = rp.z + dir.z * t;
+        if (ax) asm volatile("v_add_f32 %0, %1, %0" : "+v"(rx) : "v"(push.x));
+        else if (yz) asm volatile("v_add_f32 %0, %1, %0" : "+v"(ry) : "v"(push.y));
+        else asm volatile("v_add_f32 %0, %1, %0" : "+v"(rz) : "v"(push.z));
+        rp.x = rx; rp.y = ry; rp.z = rz;
+        return Axis{ax, yz};
+    }
+
+    static VRT_DEV void floor_both(F3 rp, F3 &pf, I3 &p) {
+        pf = F3{__builtin_floorf(rp.x), __builtin_floorf(rp.y), __builtin_floorf(rp.z)};
+        p = I3{(int)pf.x, (int)pf.y, (int)pf.z};   // v_cvt_i32_f32 of an integer-valued float: saturates, NaN -> 0, like v_cvt_flr_i32_f32
+    }
+
+    // The march loop. IOF85: every lane's starting medium is refraction byte 85 (1.0: the eye in empty space), so the
+    // medium a step leaves is the mapped byte of the cell before (see to_cell4()); otherwise empty space counts as
+    // the ray's own starting medium on the leaving side (comp:318-326).
+    template <bool IOF85>
+    static VRT_DEV bool march_loop(const KArgs &a, const Ctx &c, F3 &rp, F3 dir, F3 inv, F3 push, I3 dpos, F3 dposf, Walk &w, Found &cur,
+                                   uint32_t iof_byte, int &axis, uint32_t &px, uint32_t &py, I3 &mp) {
+        Axis ax{false, false};
+        F3 pf;
+        int i = 0, status = kGo;
+        uint32_t prev_m = 0u;
+        bool go;
+        do {
+            ax = dda_step(rp, dir, inv, push, cur.plane);
+            floor_both(rp, pf, mp);
+            const uint32_t cur_m = cur.y & 0xffu;
+            if constexpr (IOF85) prev_m = cur_m;
+            else prev_m = ((cur.x >> 24) == 0u || (cur.y & (1u << 29)) != 0u) ? iof_byte : cur_m;
+            // a ray that leaves the world misses (comp:307-310) and find() leaves `cur` alone then: nothing reads its voxel
+            // words afterwards, so the previous voxel is updated unconditionally rather than through selects
+            px = cur.x; py = cur.y;
+            status = find(a, c, mp, pf, dpos, dposf, w, cur);
+            asm volatile("" : "+v"(status));
+            bool hit = (cur.y & 0xffu) != prev_m;
+            if constexpr (!IOF85) hit = hit && status != kOutside;
+            ++i;
+            go = status != kOutside && !hit && i < 1024;
+        } while (go);
+        axis = ax.x ? 0 : (ax.yz ? 1 : 2);   // two lane masks merged per iteration by scalar instructions: off the vector port
+        // the hit flag from the registers the lane left the loop with (IOF85: outside the world `cur` is unchanged, so the
+        // bytes are equal)
+        asm volatile("" : "+v"(prev_m), "+v"(status));
+        bool hit = (cur.y & 0xffu) != prev_m;
+        if constexpr (!IOF85) hit = hit && status != kOutside;
+        return hit;
     }
 
     // hitMarching (comp:248-330)
@@ -149,53 +233,41 @@ struct Trav {
         inv.y = (__builtin_fabsf(dir.y) < 1e-8f) ? 1e20f : 1.0f / dir.y;
         inv.z = (__builtin_fabsf(dir.z) < 1e-8f) ? 1e20f : 1.0f / dir.z;
         const I3 dpos{dir.x > 0.0f ? 1 : 0, dir.y > 0.0f ? 1 : 0, dir.z > 0.0f ? 1 : 0};
+        const F3 dposf{dir.x > 0.0f ? 1.0f : 0.0f, dir.y > 0.0f ? 1.0f : 0.0f, dir.z > 0.0f ? 1.0f : 0.0f};
         const F3 sd{sign_c(dir.x), sign_c(dir.y), sign_c(dir.z)};
         const F3 push{sd.x * 0.0001f, sd.y * 0.0001f, sd.z * 0.0001f};  // comp:300-304
         Walk w;
-        I3 mp = floor_i3_fast(rp);
+        F3 pf;
+        I3 mp;
+        floor_both(rp, pf, mp);
         Found cur;
-        cur.w0 = 0u; cur.w1 = 0u; cur.plane = I3{0, 0, 0};
+        cur.x = 0u; cur.y = 85u | (1u << 23); cur.plane = F3{0.0f, 0.0f, 0.0f};   // empty space
         if (eye && eye->first_valid) {  // wave-uniform: the first lookup was made by the host
-            w.node = eye->first_node; w.cs = (uint32_t)(eye->first_s - 2);
-            w.anode = eye->first_anode; w.acs = (uint32_t)(eye->first_as - 2); w.last = mp;
-            const int t = (int)(eye->first_w1 >> 24);
-            cur.w0 = eye->first_w0;
-            cur.w1 = eye->first_w1 & 0x00ffffffu;
-            cur.plane = I3{((mp.x >> t) + dpos.x) << t, ((mp.y >> t) + dpos.y) << t, ((mp.z >> t) + dpos.z) << t};
+            w.node = eye->first_node << 9; w.cs = (uint32_t)(eye->first_s - 2);
+            w.anode = eye->first_anode << 9; w.acs = (uint32_t)(eye->first_as - 2); w.last = mp;
+            const uint32_t t = eye->first_w1 >> 24;
+            cur.x = eye->first_w0;
+            cur.y = cell4_y(eye->first_w0, eye->first_w1 & 0x00ffffffu, t + 1u);
+            const float side = __uint_as_float((127u + t) << 23), inv_side = __uint_as_float((127u - t) << 23);
+            cur.plane = F3{(__builtin_floorf(pf.x * inv_side) + dposf.x) * side, (__builtin_floorf(pf.y * inv_side) + dposf.y) * side,
+                           (__builtin_floorf(pf.z * inv_side) + dposf.z) * side};
         } else {
             reset(w);
-            if (find(a, c, mp, dpos, w, cur) == kOutside)   // comp:143-145, convention C8: zeroed data, the world's bounds
-                cur.plane = I3{dpos.x ? a.wmax[0] : a.wmin[0], dpos.y ? a.wmax[1] : a.wmin[1], dpos.z ? a.wmax[2] : a.wmin[2]};
+            if (find(a, c, mp, pf, dpos, dposf, w, cur) == kOutside) cur.plane = world_planes(a, dpos);
         }
-        uint32_t cur_b = cur.w1 & 0xffu;  // medium byte: every Found carries 0 here when alpha == 0
         int axis = 2;
-        uint32_t pw0 = 0u, pw1 = 0u;
-        int i = 0;
-        int hit = 0;
-        bool go;
-        do {
-            axis = dda_step(rp, dir, inv, push, cur.plane);
-            // the exit axis and the hit flag live in vector registers: as lane masks they would have to be merged into
-            // the masks of the lanes that have already left the loop on every iteration (three scalar instructions each)
-            asm volatile("" : "+v"(axis));
-            mp = floor_i3_fast(rp);
-            const uint32_t prev_b = cur_b ? cur_b : iof_byte;
-            // a ray that leaves the world misses (comp:307-310): nothing reads its voxel words afterwards, so they
-            // are updated unconditionally rather than through a select per register
-            pw0 = cur.w0; pw1 = cur.w1;
-            const bool inw = find(a, c, mp, dpos, w, cur) != kOutside;
-            cur_b = cur.w1 & 0xffu;
-            hit = (inw && (cur_b ? cur_b : 85u) != prev_b) ? 1 : 0;
-            asm volatile("" : "+v"(hit));
-            ++i;
-            go = inw && hit == 0 && i < 1024;
-        } while (go);
+        uint32_t px = 0u, py = 85u | (1u << 23);
+        // wave-uniform choice of the loop: all lanes start in refraction 1.0 (every primary ray of a view whose eye is in
+        // empty space; most secondary rays)
+        bool hit;
+        if (EYE85 || __builtin_amdgcn_ballot_w64(iof_byte != 85u) == 0ull) hit = march_loop<true>(a, c, rp, dir, inv, push, dpos, dposf, w, cur, iof_byte, axis, px, py, mp);
+        else hit = march_loop<false>(a, c, rp, dir, inv, push, dpos, dposf, w, cur, iof_byte, axis, px, py, mp);
         const float n = -comp(sd, axis);
         h.axis = axis; h.n = n;
-        h.map = mp; h.point = rp; h.p0 = pw0; h.p1 = pw1; h.h0 = cur.w0; h.h1 = cur.w1;
+        h.map = mp; h.point = rp;
+        h.p0 = px; h.p1 = word1_of(px, py); h.h0 = cur.x; h.h1 = word1_of(cur.x, cur.y);
         h.r_node = w.node; h.r_s = (int)w.cs; h.r_anode = w.anode; h.r_as = (int)w.acs; h.r_last = w.last;
-        asm volatile("" : "+v"(hit));   // re-read after the loop: otherwise the in-loop comparison is carried out as a merged lane mask
-        return hit != 0;
+        return hit;
     }
 
     // notInShadow (comp:333-377); the light direction is used as given
@@ -205,29 +277,34 @@ struct Trav {
         inv.y = (__builtin_fabsf(ld.y) < 1e-8f) ? 1e20f : 1.0f / ld.y;
         inv.z = (__builtin_fabsf(ld.z) < 1e-8f) ? 1e20f : 1.0f / ld.z;
         const I3 dpos{ld.x > 0.0f ? 1 : 0, ld.y > 0.0f ? 1 : 0, ld.z > 0.0f ? 1 : 0};
+        const F3 dposf{ld.x > 0.0f ? 1.0f : 0.0f, ld.y > 0.0f ? 1.0f : 0.0f, ld.z > 0.0f ? 1.0f : 0.0f};
         const F3 push{sign_c(ld.x) * 0.001f, sign_c(ld.y) * 0.001f, sign_c(ld.z) * 0.001f};
-        I3 mp = floor_i3_fast(rp);
+        F3 pf;
+        I3 mp;
+        floor_both(rp, pf, mp);
         Walk w;  // resume where the primary ray stopped: the origin is 2e-3 off its hit point
         w.node = h.r_node; w.cs = (uint32_t)h.r_s; w.anode = h.r_anode; w.acs = (uint32_t)h.r_as; w.last = h.r_last;
         Found v;
-        v.w0 = 0u; v.w1 = 0u; v.plane = I3{0, 0, 0};
-        if (find(a, c, mp, dpos, w, v) == kOutside)
-            v.plane = I3{dpos.x ? a.wmax[0] : a.wmin[0], dpos.y ? a.wmax[1] : a.wmin[1], dpos.z ? a.wmax[2] : a.wmin[2]};
+        v.x = 0u; v.y = 85u | (1u << 23); v.plane = F3{0.0f, 0.0f, 0.0f};
+        if (find(a, c, mp, pf, dpos, dposf, w, v) == kOutside) v.plane = world_planes(a, dpos);
         int lit = 1, i = 0;
         bool go;
         do {
             // occluder: alpha > 0.1 <=> alpha byte >= 26; illumination byte == 0 (comp:355)
-            const bool occluder = (v.w0 >> 24) >= 26u && ((v.w1 >> 8) & 0xffu) == 0u;
+            const bool occluder = (v.x >> 24) >= 26u && (v.y & 0xff00u) == 0u;
             lit = occluder ? 0 : lit;
             (void)dda_step(rp, ld, inv, push, v.plane);
-            mp = floor_i3_fast(rp);
+            floor_both(rp, pf, mp);
             ++i;
             go = !occluder && i < 64;
-            if (go) go = find(a, c, mp, dpos, w, v) != kOutside;
+            if (go) go = find(a, c, mp, pf, dpos, dposf, w, v) != kOutside;
         } while (go);
         return lit;
     }
 };
+
+using Trav = TravT<true>;       // modes 0, 1 when the eye is in empty space (else the dispatcher takes v3)
+using TravAny = TravT<false>;   // the full path tracer
 
 }  // namespace v4
 }  // namespace vrt

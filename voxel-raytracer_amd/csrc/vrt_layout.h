@@ -72,6 +72,25 @@ struct WideTree {
 constexpr uint32_t kWideInternal = 0x80000000u;
 constexpr int kMaxWideRoots = 8;
 
+// The same cell as the v4 kernels read it (vrt_kernels_v4.hip.h), chosen so that the march loop needs the cheapest
+// instructions gfx950 has for what it does with a cell (profiles/r02_valu_rate.txt):
+//   subdivided : w0 = BYTE offset of the child wide node (node * 512), w1 = 0
+//   leaf/empty : w0 = the leaf word 0 (R | G<<8 | B<<16 | alpha<<24), unchanged
+//                w1[ 7: 0] = medium byte: the refraction byte, with 85 (refraction 1.0, what the shader substitutes for
+//                            empty space, comp:318-326) where the layout above stores 0 -- two media differ iff these differ
+//                w1[15: 8] = illumination byte, w1[22:16] = k bits 6..0, w1[28] = k bit 7
+//                w1[27:23] = t + 1 (t = log2 side of the octree node found): (w1 & 0x0f800000) + 0x3f000000 is the float
+//                            2^t and 0x40000000 - (w1 & 0x0f800000) the float 2^-t, so the node's planes are four plain
+//                            f32 operations per axis on floor(p) instead of integer shifts and conversions
+//                w1[29]    = the refraction byte was 0 although alpha > 0 (restores word 1 exactly for shading)
+// t + 1 >= 1 tells a leaf/empty cell from a subdivided one.
+inline WideCell to_cell4(WideCell c) {
+    if (c.w1 & kWideInternal) return WideCell{c.w0 << 9, 0u};
+    const uint32_t t = (c.w1 >> 24) & 31u, b = c.w1 & 0xffu, illum = (c.w1 >> 8) & 0xffu, k = (c.w1 >> 16) & 0xffu;
+    const uint32_t raw0 = (b == 0u && (c.w0 >> 24) != 0u) ? 1u : 0u;
+    return WideCell{c.w0, (b ? b : 85u) | (illum << 8) | ((k & 0x7fu) << 16) | ((t + 1u) << 23) | ((k >> 7) << 28) | (raw0 << 29)};
+}
+
 // Returns false when the scene cannot be expressed (an internal node of unit size inside an aligned
 // cube, or more than kMaxWideRoots roots): the dispatcher then uses the record-array kernels.
 bool build_wide(const std::vector<Record> &records, const int wmin[3], const int wmax[3], WideTree &out, std::string &why);
