@@ -80,3 +80,28 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` outside torchrun must become a two-rank job by itself (it printed an
+    n_gpus: 1 line): the plan-only mode runs the launcher, the rendezvous and the shard plan without a GPU."""
+    import json
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-plan"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["launcher"] == "self-spawned" and d["collective_backend"] == "gloo"
+    assert d["gather"] == "frame" and d["rows_per_rank"] == [544, 536] and d["rows_sum_checked_across_ranks"] is True
+    # one rank: no launcher, no collective
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-plan"], env=env, capture_output=True, text=True, timeout=300)
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["launcher"] == "single" and d["gather"] == "final" and d["rows_per_rank"] == [1080]
+    # started under a launcher whose world size disagrees with --gpus: refuse instead of printing a line for another job
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-plan"],
+                       env=dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -422,6 +422,59 @@ def test_materials_highlight_and_translucent_fallback(ctx, V, O):
             _assert_same(idd, ref_id, f"materials pose {pose} hl {hl} mode {mode} id/dist")
 
 
+def test_full_path_tracer_as_two_kernels(ctx, V, O, golden, product_scenes):
+    """VRT_MODE_FULL runs as trace_kernel<3> + bounce_kernel (deferred diffuse bounces marched by persistent waves whose
+    lanes are refilled from queues): every frame must equal the one-kernel form's and the oracle's -- whole frames, row
+    shards (compact buffers, ragged tile counts), repeated launches (queue counters reset per launch), two streams at once
+    (a queue set per stream), a launch without a colour image."""
+    import torch
+    try:
+        ctx.set_full_split(True)
+    except V.VrtError:
+        pytest.skip("the two-kernel form is an experiment kept in A/B builds only (make AB=1)")
+    for name, size in (("dragon", (256, 144)), ("nature", (203, 117)), ("terrain", (240, 136))):
+        tex, dim = product_scenes[name]
+        g = golden["frames"]["frames"][{"dragon": "dragon_256x144/mode2", "nature": "nature_200x112/mode2", "terrain": "terrain_240x136/mode2"}[name]]
+        W, H = size
+        cam = _setup(ctx, V, tex, dim, g["pose"], W, H)
+        ref_rgba, ref_id, _ = _oracle_frame(O, tex, dim, cam, W, H, 2)
+        for split in (True, False, True):
+            ctx.set_full_split(split)
+            for _ in range(3):   # scheduled flavours: plain, measuring, ordered
+                rgba, idd = ctx.dispatch(W, H, 2)
+                _assert_same(rgba, ref_rgba, f"{name} full split={split} rgba8")
+                _assert_same(idd, ref_id, f"{name} full split={split} id/dist")
+        # shards into compact buffers on two streams at once
+        dev = torch.device("cuda:0")
+        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        for tile_rows, n_shards in ((8, 2), (5, 3)):
+            bufs = []
+            for s_ in range(n_shards):
+                rows = V.shard_row_indices(H, tile_rows, s_, n_shards)
+                bufs.append((rows, torch.zeros((max(1, len(rows)), W), dtype=torch.int32, device=dev),
+                             torch.zeros((max(1, len(rows)), W, 2), dtype=torch.int32, device=dev)))
+            torch.cuda.synchronize()
+            for rep in range(2):
+                for s_, (rows, sr, si) in enumerate(bufs):
+                    if rows:
+                        ctx.dispatch_shard(W, H, tile_rows, s_, n_shards, 2, sr.data_ptr(), si.data_ptr(), streams[s_ % 2].cuda_stream)
+            torch.cuda.synchronize()
+            out_rgba, out_id = np.zeros_like(ref_rgba), np.zeros_like(ref_id)
+            for rows, sr, si in bufs:
+                if rows:
+                    out_rgba[rows] = sr.cpu().numpy().view(np.uint8).reshape(len(rows), W, 4)
+                    out_id[rows] = si.cpu().numpy()
+            _assert_same(out_rgba, ref_rgba, f"{name} full shards {tile_rows}/{n_shards} rgba8")
+            _assert_same(out_id, ref_id, f"{name} full shards {tile_rows}/{n_shards} id/dist")
+        # id image only: nothing for the bounce kernel to finish
+        d_id = torch.zeros((H, W, 2), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ctx.dispatch_rows(W, H, 0, H, 2, None, d_id.data_ptr())
+        ctx.synchronize()
+        _assert_same(d_id.cpu().numpy(), ref_id, f"{name} full id only")
+    ctx.set_full_split(False)
+
+
 def test_row_sharding_properties_at_full_size(ctx, V, golden, product_scenes):
     """N-shard result == 1-GPU result byte for byte (virtual shards on one device), at 1920x1080."""
     import torch

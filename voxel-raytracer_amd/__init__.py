@@ -146,6 +146,8 @@ def hip_lib():
         L.vrt_device.argtypes = [C.c_void_p]
         L.vrt_set_variant.argtypes = [C.c_void_p, C.c_int]
         L.vrt_variant_available.argtypes = [C.c_int]
+        L.vrt_debug_set_full_split.argtypes = [C.c_void_p, C.c_int]
+        L.vrt_debug_set_bounce.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.vrt_version.restype = C.c_char_p
         L.vrt_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.vrt_debug_build_layout.restype = C.c_long
@@ -505,6 +507,13 @@ class Context:
         if n < 0:
             self._chk(n)
         return buf[:min(n, cap)].copy()
+
+    def set_full_split(self, on):
+        """A/B: the full path tracer as two kernels (default) or as round 1's one kernel"""
+        self._chk(hip_lib().vrt_debug_set_full_split(self._h, 1 if on else 0))
+
+    def set_bounce(self, refill_below, waves_per_simd):
+        self._chk(hip_lib().vrt_debug_set_bounce(self._h, refill_below, waves_per_simd))
 
     def set_denoise_variant(self, v):
         """Pixels per lane of the display-pass kernel: 0 = two (default), 1 = one."""

@@ -16,6 +16,9 @@
 #include "vrt_kernels_wide.hip.h"
 #include "vrt_kernels_v4.hip.h"
 #include "vrt_full.hip.h"
+#ifdef VRT_AB_VARIANTS
+#include "vrt_bounce.hip.h"   // the two-kernel full path tracer: an experiment that lost (profiles/r02_b_*), kept for A/B builds
+#endif
 #include "vrt_denoise.hip.h"
 #include "vrt_layout.h"
 
@@ -129,6 +132,18 @@ struct vrt_ctx {
     uint2 *d_cells = nullptr;     // cells_capacity cells in the layout of vrt_layout.h, then as many in the v4 form (cells4)
     uint32_t *d_roots = nullptr;  // 16 words: record and wide node of each wide root (vrt_common.hip.h KArgs::root_table)
     size_t cells_capacity = 0;
+    // the full path tracer as two kernels (vrt_bounce.hip.h): deferred-bounce queues, sized for the largest launch so far
+    bool full_split = false;
+    int bounce_refill_below = 40, bounce_waves_per_simd = 6;   // vrt_debug_set_bounce (tools sweep them)
+    struct DeferQueues {                  // one set per stream: launches on different streams may overlap
+        hipStream_t stream = nullptr;
+        float *rec = nullptr;
+        uint32_t *count = nullptr;        // 2 * kDeferQueues counters, kDeferStride words apart: records written, records handed out
+        size_t cap = 0;                   // records per queue
+        uint64_t last_use = 0;
+    };
+    std::vector<DeferQueues> defer;
+    uint64_t defer_tick = 0;
     // feedback scheduling of the default kernel (see SchedState)
     int sched_period = 16;                   // every n-th launch of a shape measures its tiles; 0 = off
     std::vector<SchedState> sched;
@@ -166,7 +181,7 @@ hipError_t launch_one(const vrt::KArgs &a, const vrt::ViewSet &vs, int grid, siz
             raised = true;
         }
     }
-    if (ev0)
+    if (ev0 || ev1)   // either may be null: the two-kernel full path tracer times from the first kernel's start to the second one's end
         hipExtLaunchKernelGGL(kernel, dim3(grid, a.n_views), dim3(BLOCK), lds_bytes, s, ev0, ev1, 0, a, vs);
     else
         hipLaunchKernelGGL(kernel, dim3(grid, a.n_views), dim3(BLOCK), lds_bytes, s, a, vs);
@@ -415,6 +430,9 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     a.root0_shift = a.n_roots ? c->wide.roots[0].shift : 0;
     a.group_order = nullptr;
     a.tile_cost = nullptr;
+    a.defer_rec = nullptr;
+    a.defer_count = nullptr;
+    a.defer_cap = 0;
 
     const int th = 64 / v.tw;
     const long tiles = (long)((width + v.tw - 1) / v.tw) * (long)((n_rows + th - 1) / th);
@@ -459,6 +477,57 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     const hipEvent_t ev0 = prof ? c->prof_events[2 * c->prof_count] : nullptr;
     const hipEvent_t ev1 = prof ? c->prof_events[2 * c->prof_count + 1] : nullptr;
     hipError_t e;
+    // The full path tracer as two kernels (vrt_bounce.hip.h): the default traversal, one view, a scene with a wide form.
+    const bool split = VRT_AB && mode == VRT_MODE_FULL && c->full_split && c->wide_ok && v.trav == 3 && v.block == 64 && n_views == 1 && c->variant == 0;
+    if (split) {
+        const size_t cap = (size_t)((tiles + vrt::kDeferQueues - 1) / vrt::kDeferQueues) * 64;   // every pixel of a queue's tiles may defer
+        vrt_ctx::DeferQueues *dq = nullptr;
+        for (auto &d : c->defer)
+            if (d.stream == s) dq = &d;
+        if (!dq) {
+            if (c->defer.size() < 8) {
+                c->defer.emplace_back();
+                dq = &c->defer.back();
+            } else {   // recycle the least recently used set: its launches may still be in flight on its stream
+                for (auto &d : c->defer)
+                    if (!dq || d.last_use < dq->last_use) dq = &d;
+                VRT_HIP(c, hipStreamSynchronize(dq->stream));
+            }
+            dq->stream = s;
+        }
+        if (cap > dq->cap) {
+            VRT_HIP(c, hipStreamSynchronize(s));   // launches in flight on this stream still use the old queues
+            float *fresh = nullptr;
+            VRT_HIP(c, hipMalloc((void **)&fresh, cap * vrt::kDeferQueues * vrt::kDeferPlanes * sizeof(float)));
+            if (dq->rec) (void)hipFree(dq->rec);
+            dq->rec = fresh;
+            dq->cap = cap;
+        }
+        if (!dq->count) VRT_HIP(c, hipMalloc((void **)&dq->count, 2 * vrt::kDeferQueues * vrt::kDeferStride * sizeof(uint32_t)));
+        dq->last_use = ++c->defer_tick;
+        VRT_HIP(c, hipMemsetAsync(dq->count, 0, 2 * vrt::kDeferQueues * vrt::kDeferStride * sizeof(uint32_t), s));
+        a.defer_rec = dq->rec;
+        a.defer_count = dq->count;
+        a.defer_cap = (uint32_t)dq->cap;
+    }
+#if VRT_AB
+    if (split) {
+        e = launch_sched<3, vrt::v3::Trav, 8, 64, 5>(a, vs, (int)grid, 0, s, ev0, nullptr);
+        if (e == hipSuccess) {
+            vrt::bounce::Args b;
+            b.out_rgba = vs.v[0].out_rgba;
+            b.refill_below = c->bounce_refill_below;
+            if (b.out_rgba) {   // without a colour image there is nothing for the bounce rays to finish
+                const int waves = c->n_cus * 4 * c->bounce_waves_per_simd;   // the chip filled once (six waves per SIMD: the kernel's register budget)
+                if (ev1) hipExtLaunchKernelGGL(vrt::bounce::bounce_kernel, dim3(waves), dim3(64), 0, s, nullptr, ev1, 0, a, b);
+                else hipLaunchKernelGGL(vrt::bounce::bounce_kernel, dim3(waves), dim3(64), 0, s, a, b);
+                e = hipGetLastError();
+            } else if (ev1) {
+                e = hipEventRecord(ev1, s);
+            }
+        }
+    } else
+#endif
     if (mode == VRT_MODE_FULL) {
         if (v.trav == 3 && v.block == 64) e = launch_sched<2, vrt::v3::Trav, 8, 64, 5>(a, vs, (int)grid, 0, s, ev0, ev1);
 #if VRT_AB
@@ -552,6 +621,10 @@ void vrt_destroy(vrt_ctx *c) {
     if (c->d_rgba) (void)hipFree(c->d_rgba);
     if (c->d_id) (void)hipFree(c->d_id);
     if (c->d_shown) (void)hipFree(c->d_shown);
+    for (auto &d : c->defer) {
+        (void)hipFree(d.rec);
+        (void)hipFree(d.count);
+    }
     if (!c->sched.empty()) (void)hipDeviceSynchronize();  // their launches may be on the caller's streams
     for (SchedState &st : c->sched) {
         (void)hipFree(st.d_cost);
@@ -1112,6 +1185,21 @@ void *vrt_stream(vrt_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int vrt_device(const vrt_ctx *c) { return c ? c->device : VRT_E_INVALID; }
 
 // Arithmetic-contract probe (see math_probe_kernel): host arrays in/out, synchronous.
+// A/B switch (tests, tools): 0 runs the full path tracer as the one kernel of round 1, 1 (default) as two (vrt_bounce.hip.h)
+int vrt_debug_set_full_split(vrt_ctx *c, int on) {
+    if (!c) return VRT_E_INVALID;
+    if (on && !VRT_AB) return fail(c, VRT_E_INVALID, "vrt_debug_set_full_split: the two-kernel form exists in A/B builds only (make AB=1)");
+    c->full_split = on != 0;
+    return VRT_OK;
+}
+
+int vrt_debug_set_bounce(vrt_ctx *c, int refill_below, int waves_per_simd) {
+    if (!c || refill_below < 1 || refill_below > 65 || waves_per_simd < 1 || waves_per_simd > 8) return VRT_E_INVALID;
+    c->bounce_refill_below = refill_below;
+    c->bounce_waves_per_simd = waves_per_simd;
+    return VRT_OK;
+}
+
 int vrt_debug_set_denoise_variant(vrt_ctx *c, int v) {
     if (!c || v < 0 || v > 1) return VRT_E_INVALID;
     c->denoise_variant = v;

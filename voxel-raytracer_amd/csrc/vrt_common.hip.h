@@ -82,7 +82,17 @@ struct KArgs {
     // tile_cost[tile], from which tile_order_kernel derives the next order.
     const uint32_t *group_order;
     uint32_t *tile_cost;
+    // Deferred diffuse bounces of the full path tracer (MODE 3 of trace_kernel, vrt_bounce.hip.h): kDeferQueues queues of
+    // defer_cap ray records each, structure of arrays (plane p of queue q starts at defer_rec + (p * kDeferQueues + q) * defer_cap),
+    // defer_count[q * kDeferStride] = records in queue q, defer_count[(kDeferQueues + q) * kDeferStride] = records already
+    // handed out by bounce_kernel: every counter in a cache line of its own (atomics on one line are served one at a time).
+    float *defer_rec;
+    uint32_t *defer_count;
+    uint32_t defer_cap;
 };
+constexpr uint32_t kDeferQueues = 64;   // a wave appends to queue (tile % 64): sixty-four counters share the atomic traffic
+constexpr uint32_t kDeferStride = 64;   // words between two counters: 256 bytes
+constexpr uint32_t kDeferPlanes = 19;   // o[3] d[3] tint[3] fc[3] iof weight mc[3] md out_offset
 
 #define VRT_DEV __device__ __forceinline__
 
@@ -206,8 +216,9 @@ struct LateOut {
     uint32_t *out_rgba;
     int2 *out_id;
     int width, compact;
+    bool skip_rgba;   // MODE 3: the pixel's colour is finished by bounce_kernel
 };
-VRT_DEV LateOut late_out(LateArgs la, LateView lv) { return LateOut{lv->out_rgba, lv->out_id, la->width, la->compact}; }
+VRT_DEV LateOut late_out(LateArgs la, LateView lv) { return LateOut{lv->out_rgba, lv->out_id, la->width, la->compact, false}; }
 
 // One pixel: ray generation (comp:624-641), primary-ray pathTrace, packing of the two outputs.
 // TRAV supplies the traversal: march(), shadow(). MODE: 0 primary, 1 primary + shadow ray.
@@ -345,9 +356,10 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
     idd = make_int2(voxel_id, pixel_dist);
 }
 
-namespace full {  // MODE 2, defined in vrt_full.hip.h
-template <class TRAV>
-__device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, int px, int py, uint32_t &rgba, int2 &idd, LateOut &lo);
+namespace full {  // MODE 2 and 3 (3: the last diffuse bounce of a pixel goes to a queue for bounce_kernel), defined in vrt_full.hip.h
+template <class TRAV, bool DEFER>
+__device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, int px, int py, uint32_t &rgba, int2 &idd, LateOut &lo,
+                                 uint32_t queue, uint32_t out_offset);
 }
 
 // One lane per pixel; a wave covers a TW x TH pixel tile (TW*TH == 64) so the 64 rays of a wave stay spatially
@@ -403,12 +415,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
             uint32_t rgba;
             int2 idd;
             const View &vw = vs.v[blockIdx.y];
-            LateOut lo;  // MODE 1, 2: the output side of the arguments, re-read after the trace rather than kept in registers across it
-            if constexpr (MODE == 2) full::trace_pixel_full<TRAV>(a, vw, tc_, px, py, rgba, idd, lo);
+            LateOut lo;  // MODE 1, 2, 3: the output side of the arguments, re-read after the trace rather than kept in registers across it
+            lo.skip_rgba = false;
+            if constexpr (MODE >= 2)
+                full::trace_pixel_full<TRAV, MODE == 3>(a, vw, tc_, px, py, rgba, idd, lo, (uint32_t)tile % kDeferQueues,
+                                                        (uint32_t)((a.compact ? j : py) * a.width + px));
             else trace_pixel<MODE, TRAV>(a, vw, tc_, px, py, rgba, idd, lo);
-            if constexpr (MODE == 0) lo = LateOut{vw.out_rgba, vw.out_id, a.width, a.compact};
+            if constexpr (MODE == 0) lo = LateOut{vw.out_rgba, vw.out_id, a.width, a.compact, false};
             size_t o = (size_t)(lo.compact ? j : py) * (size_t)lo.width + (size_t)px;
-            if (lo.out_rgba) lo.out_rgba[o] = rgba;
+            if (lo.out_rgba && !lo.skip_rgba) lo.out_rgba[o] = rgba;
             if (lo.out_id) lo.out_id[o] = idd;
         }
         if constexpr (SCHED & 2) {  // the wave has reconverged: this is the time its slowest ray took
