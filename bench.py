@@ -331,6 +331,65 @@ def main():
         other = {"gather": o_mode, "value": round(W * H * args.steps / eo / 1e6, 2), "unit": "Mrays/s",
                  "ms_per_step": round(eo / args.steps * 1e3, 5), "same_pixels": same}
 
+    # several GPUs: the same delivery with NO collective -- every rank's kernels store their tiles straight into the root's
+    # frame through an IPC mapping (xGMI peer stores), ordered by stream flags (sharding.PeerFramePipeline): to rank 0,
+    # and with the root rotating over the ranks (frame f assembled on rank f % N). A failure of the mappings is reported,
+    # never fatal: the RCCL regions above stand on their own.
+    peer = {}
+    if (world > 1 or os.environ.get("VRT_BENCH_PEER_AT_ONE")) and not os.environ.get("VRT_BENCH_NO_PEER"):
+        frames_g = json.load(open(os.path.join(ROOT, "tests", "golden", "frames.json")))["frames"]
+        gkey = GOLDEN_KEY[args.map] + ("_full" if mode == 2 and args.map == "dragon" else "") + f"/mode{mode}"
+        gg = frames_g.get(gkey)
+        for name, rotate in (("peer_store_rank0", False), ("peer_store_rotating_root", True)):
+            pp = None
+            try:
+                pp = shd.PeerFramePipeline(ctx, plan, n_buf=4, rotate=rotate)
+                why = pp.rehearse()
+                if why:
+                    peer[name] = {"error": why}
+                    continue
+
+                def tiles(d_rgba, d_id, stream):
+                    ctx.dispatch_tiles(W, H, args.tile_rows, rank, world, mode, d_rgba, d_id, stream)
+                for _ in range(args.warmup):
+                    pp.step(tiles)
+                pp.drain()
+                if world > 1:
+                    dist.barrier()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    pp.step(tiles)
+                pp.drain()
+                if world > 1:
+                    dist.barrier()
+                torch.cuda.synchronize(dev)
+                ep = time.perf_counter() - t0
+                if world > 1:
+                    t = torch.tensor([ep], dtype=torch.float64, device="cpu" if via_host else dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    ep = float(t.item())
+                ok = None
+                last = pp.last_frame()
+                if last is not None and gg is not None and (gg["width"], gg["height"]) == (W, H):
+                    ok = ("%016x" % V.fnv1a64(last[0]) == gg["rgba_fnv1a64"] and "%016x" % V.fnv1a64(last[1]) == gg["id_dist_fnv1a64"])
+                oks = [ok]
+                if world > 1:
+                    oks = [None] * world
+                    dist.all_gather_object(oks, ok)
+                checked = [o for o in oks if o is not None]
+                peer[name] = {"value": round(W * H * args.steps / ep / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(ep / args.steps * 1e3, 5),
+                              "frames_match_oracle_golden": (all(checked) if checked else None), "roots_checked": len(checked),
+                              "slots": pp.n_buf}
+            except Exception as ex:  # noqa: BLE001 -- any failure of the IPC path is a report line, not the end of the bench
+                peer[name] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+            finally:
+                if pp is not None:
+                    try:
+                        pp.close()
+                    except Exception:  # noqa: BLE001
+                        pass
+
     # one GPU, informational: the same K frames rotating through four streams (no per-launch events; the figure the
     # headline would become if overlapped launches were allowed to blur the per-kernel duration the roofline uses)
     overlapped = None
@@ -394,6 +453,16 @@ def main():
         rays = W * H
         ms_per_step = elapsed / args.steps * 1e3
         value = rays * args.steps / elapsed / 1e6
+        # several ranks: two ways deliver every frame to rank 0 -- the RCCL gather timed above and the peer stores; the
+        # headline is the faster one whose frames were verified, the other stays beside it
+        delivery_used = None
+        rccl_frame = None
+        if world > 1 and gather == "frame":
+            rccl_frame = {"value": round(value, 2), "unit": "Mrays/s", "ms_per_step": round(ms_per_step, 5)}
+            delivery_used = "rccl_gather"
+            p0 = peer.get("peer_store_rank0") or {}
+            if p0.get("frames_match_oracle_golden") and p0.get("value", 0) > value:
+                value, ms_per_step, delivery_used = p0["value"], p0["ms_per_step"], "peer_store_rank0"
         roofline = None
         issue = None
         if known and len(kernel_ms):
@@ -446,14 +515,19 @@ def main():
                      "FastNoiseLite(1337) Perlin height field fixture (tests/golden/terrain.json), reference terrain generator") +
                     ", fixed synthetic camera pose",
             "config": {"workload": f"{args.map}.vox {W}x{H} {args.mode} rays, pose {pose}", "mode": args.mode,
-                       "sharding": f"interleaved {args.tile_rows}-row tiles over {world} rank(s); " + delivery,
-                       "gather": gather, "streams": n_streams, "tile_scheduling_period": args.sched_period,
+                       "sharding": f"interleaved {args.tile_rows}-row tiles over {world} rank(s); " + (
+                           "every frame delivered to rank 0 inside the timed region by the ranks' own kernel stores through IPC "
+                           "mappings of rank 0's frame buffers (xGMI peer stores, stream flags, four slots)"
+                           if delivery_used == "peer_store_rank0" else delivery),
+                       "gather": gather, "delivery": delivery_used, "streams": n_streams, "tile_scheduling_period": args.sched_period,
                        "variant": args.variant, "collective_backend": args.backend if world > 1 else None,
                        "launcher": launcher},
             "roofline": roofline,
             "issue_roofline": issue,
             "pixels_match_oracle_golden": check,
             ("sharded_resident" if gather == "frame" else "every_frame_delivered"): other,
+            "rccl_gather_every_frame": rccl_frame,
+            "peer_delivery": peer or None,
             "overlapped_frames": overlapped,
             "batched_views": batched,
         }

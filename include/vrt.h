@@ -132,6 +132,60 @@ int vrt_dispatch_shard(vrt_ctx *ctx, int width, int height, int tile_rows, int s
                        void *d_rgba8, void *d_id_dist, void *stream);
 /* rows (and pixels = rows*width) a shard owns under that scheme */
 int vrt_shard_rows(int height, int tile_rows, int shard, int n_shards);
+/* The same tiles written at their place in a FULL frame (width*height pixels) instead of a compact buffer: the frame
+ * may live on this device, on a peer device whose memory this one can reach (hipDeviceEnablePeerAccess, or an
+ * allocation opened with vrt_ipc_open in another process) -- the shards of one frame then land in ONE framebuffer
+ * with no gather step: the kernels' own stores cross xGMI. */
+int vrt_dispatch_tiles(vrt_ctx *ctx, int width, int height, int tile_rows, int shard, int n_shards, int mode,
+                       void *d_frame_rgba8, void *d_frame_id_dist, void *stream);
+
+/* Device memory that other processes of the node can map (one process per GPU: the frame lives on one rank, the
+ * others store into it). vrt_device_alloc is hipMalloc on the context's device (zero-filled); vrt_ipc_export fills a
+ * 64-byte handle another process passes to vrt_ipc_open, which returns the address of the same memory in ITS address
+ * space (on its context's device: peer access over xGMI); vrt_ipc_close unmaps it. Needs
+ * HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf handles) in both processes. */
+#define VRT_IPC_HANDLE_BYTES 64
+int vrt_device_alloc(vrt_ctx *ctx, size_t bytes, void **d_ptr);
+int vrt_device_free(vrt_ctx *ctx, void *d_ptr);
+/* synchronous copies between such memory and the host, after the work enqueued on `stream` (NULL: the context's) */
+int vrt_device_read(vrt_ctx *ctx, const void *d_ptr, void *host, size_t bytes, void *stream);
+int vrt_device_write(vrt_ctx *ctx, void *d_ptr, const void *host, size_t bytes, void *stream);
+int vrt_ipc_export(vrt_ctx *ctx, void *d_ptr, uint8_t handle[VRT_IPC_HANDLE_BYTES]);
+int vrt_ipc_open(vrt_ctx *ctx, const uint8_t handle[VRT_IPC_HANDLE_BYTES], void **d_ptr);
+int vrt_ipc_close(vrt_ctx *ctx, void *d_ptr);
+/* Stream-ordered flags in device memory (a uint32 per flag): vrt_stream_write_flag makes `stream` store `value`
+ * once everything enqueued before it has finished; vrt_stream_wait_flag makes `stream` wait until *d_flag >= value.
+ * With the flag in an IPC-mapped allocation this is how a producer rank tells the consumer rank "my tiles of frame i
+ * have landed" (and the consumer tells it "buffer k is free again") without the host or a collective in the loop. */
+int vrt_stream_write_flag(vrt_ctx *ctx, void *d_flag, uint32_t value, void *stream);
+int vrt_stream_wait_flag(vrt_ctx *ctx, void *d_flag, uint32_t value, void *stream);
+
+/* ---- several GPUs behind one handle (reference: one GL context, src/main.cpp:432-474) -------------------------------
+ * vrt_create_multi(n, device_ids) makes one context per device in THIS process (no Python, no launcher) and enables
+ * peer access from every device to device_ids[0]. Scene, camera and uniforms are replicated by the vrt_multi_* setters.
+ * vrt_multi_dispatch traces one frame, the devices sharing it by interleaved tile_rows-row tiles, into full-frame DEVICE
+ * buffers on device_ids[0] (vrt_multi_frame_alloc): delivery VRT_DELIVER_PEER_STORE lets every device's kernel store its
+ * tiles straight into those buffers (peer mappings over xGMI, no gather); VRT_DELIVER_GATHER traces into per-device
+ * compact shard buffers and lets device 0 pull and un-interleave them with one copy kernel per image (reads over xGMI).
+ * Returns after enqueueing; vrt_multi_synchronize waits for all devices. The frame is complete on device_ids[0] once
+ * the call's work on stream vrt_multi_stream(m) has finished. */
+typedef struct vrt_multi vrt_multi;
+#define VRT_DELIVER_PEER_STORE 0
+#define VRT_DELIVER_GATHER 1
+int vrt_create_multi(int n_devices, const int *device_ids, vrt_multi **out);
+void vrt_destroy_multi(vrt_multi *m);
+const char *vrt_multi_last_error(const vrt_multi *m);   /* m may be NULL: the last failed vrt_create_multi on this thread */
+int vrt_multi_devices(const vrt_multi *m);
+vrt_ctx *vrt_multi_context(vrt_multi *m, int i);        /* the i-th device's context (for per-device calls) */
+int vrt_multi_upload_octree(vrt_multi *m, const uint8_t *texels, size_t used_bytes, uint32_t tex_dim);
+int vrt_multi_set_camera(vrt_multi *m, const float inv_projection[16], const float inv_view[16], const float camera_pos[4]);
+int vrt_multi_set_params(vrt_multi *m, const vrt_params *p);
+int vrt_multi_frame_alloc(vrt_multi *m, int width, int height, void **d_rgba8, void **d_id_dist);   /* on device_ids[0] */
+int vrt_multi_frame_free(vrt_multi *m, void *d_rgba8, void *d_id_dist);
+int vrt_multi_dispatch(vrt_multi *m, int width, int height, int tile_rows, int mode, int delivery, void *d_rgba8,
+                       void *d_id_dist);
+int vrt_multi_synchronize(vrt_multi *m);
+void *vrt_multi_stream(vrt_multi *m);                    /* device_ids[0]'s stream: consumers of the frame order themselves after it */
 
 /* EXTENSION: up to 4 views of the uploaded scene in ONE launch -- frames that are known together (a stereo pair,
  * the next frames of a camera path, the views of a rig). Each view brings its own camera block (what

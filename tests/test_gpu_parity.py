@@ -516,6 +516,106 @@ def test_row_sharding_properties_at_full_size(ctx, V, golden, product_scenes):
     assert np.array_equal(again_rgba, full_rgba) and np.array_equal(again_id, full_id)
 
 
+def test_tiles_into_one_frame_ipc_and_flags(ctx, V, golden, product_scenes):
+    """vrt_dispatch_tiles: the shards of a frame written at their place in ONE full frame (what a peer GPU does through an
+    xGMI mapping); device memory exported to another process and stored into from there (the one-process-per-GPU form:
+    here both processes sit on the one GPU of the box); stream-ordered flags."""
+    import subprocess
+    import sys
+    import textwrap
+    from conftest import ROOT
+    g = golden["frames"]["frames"]["dragon_256x144/mode1"]
+    tex, dim = product_scenes["dragon"]
+    W, H = g["width"], g["height"]
+    _setup(ctx, V, tex, dim, g["pose"], W, H)
+    want_rgba, want_id = ctx.dispatch(W, H, 1)
+    assert "%016x" % V.fnv1a64(want_rgba) == g["rgba_fnv1a64"]
+    d_rgba, d_id, d_flag = ctx.device_alloc(W * H * 4), ctx.device_alloc(W * H * 8), ctx.device_alloc(256)
+    try:
+        for tile_rows, n_shards in ((8, 3), (5, 4), (H, 2)):
+            ctx.device_write(d_rgba, np.zeros(W * H, np.uint32))
+            ctx.device_write(d_id, np.zeros(2 * W * H, np.int32))
+            for s_ in range(n_shards):
+                ctx.dispatch_tiles(W, H, tile_rows, s_, n_shards, 1, d_rgba, d_id)
+            _assert_same(ctx.device_read(d_rgba, (H, W, 4), np.uint8), want_rgba, f"tiles {tile_rows}/{n_shards} rgba8")
+            _assert_same(ctx.device_read(d_id, (H, W, 2), np.int32), want_id, f"tiles {tile_rows}/{n_shards} id/dist")
+        # flags: a wait for a value the same stream wrote before it passes; values are kept
+        ctx.stream_write_flag(d_flag, 7)
+        ctx.stream_wait_flag(d_flag, 7)
+        ctx.stream_wait_flag(d_flag, 3)
+        ctx.synchronize()
+        assert int(ctx.device_read(d_flag, (1,), np.uint32)[0]) == 7
+        # another process maps the frame and traces the odd shards into it, then raises the flag
+        ctx.device_write(d_rgba, np.zeros(W * H, np.uint32))
+        ctx.device_write(d_id, np.zeros(2 * W * H, np.int32))
+        ctx.device_write(d_flag, np.zeros(1, np.uint32))
+        handles = [ctx.ipc_export(p).hex() for p in (d_rgba, d_id, d_flag)]
+        child = textwrap.dedent(f"""
+            import os, sys
+            sys.path.insert(0, {ROOT!r})
+            import numpy as np
+            import vrt_import
+            V = vrt_import.vrt()
+            w = V.World(); assert w.load_vox(os.path.join({ROOT!r}, "tests/golden/maps/dragon.vox"))
+            tex, dim = w.flatten()
+            c = V.Context(0)
+            c.upload_octree(tex, dim)
+            ip, iv, cp, _ = V.camera_block({tuple(g["pose"][:3])!r}, {g["pose"][3]!r}, {g["pose"][4]!r}, {W}, {H})
+            c.set_camera(ip, iv, cp)
+            ptrs = [c.ipc_open(bytes.fromhex(h)) for h in {handles!r}]
+            c.dispatch_tiles({W}, {H}, 8, 1, 2, 1, ptrs[0], ptrs[1])
+            c.stream_write_flag(ptrs[2], 41)
+            c.synchronize()
+            for p in ptrs: c.ipc_close(p)
+            c.close()
+            print("child ok")
+        """)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        ctx.dispatch_tiles(W, H, 8, 0, 2, 1, d_rgba, d_id)     # this process: the even tiles
+        ctx.synchronize()
+        r = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+        ctx.stream_wait_flag(d_flag, 41)
+        _assert_same(ctx.device_read(d_rgba, (H, W, 4), np.uint8), want_rgba, "two processes, one frame: rgba8")
+        _assert_same(ctx.device_read(d_id, (H, W, 2), np.int32), want_id, "two processes, one frame: id/dist")
+    finally:
+        for p in (d_rgba, d_id, d_flag):
+            ctx.device_free(p)
+
+
+def test_multi_gpu_boundary_rehearsed_on_one_device(V, golden, product_scenes):
+    """vrt_create_multi / vrt_multi_dispatch (include/vrt.h): one context per listed device, the frame assembled on the
+    first. The box has one GPU, so the device is listed one, two and three times: every context then shares device 0, which
+    exercises everything but the xGMI hop itself (peer enabling is skipped for a repeated device)."""
+    tex, dim = product_scenes["dragon"]
+    for key in ("dragon_256x144/mode1", "dragon_256x144/mode2"):
+        g = golden["frames"]["frames"][key]
+        W, H = g["width"], g["height"]
+        ip, iv, cp, _ = V.camera_block(g["pose"][:3], g["pose"][3], g["pose"][4], W, H)
+        for devices in ([0], [0, 0], [0, 0, 0]):
+            m = V.Multi(devices)
+            try:
+                m.upload_octree(tex, dim)
+                m.set_camera(ip, iv, cp)
+                d_rgba, d_id = m.frame_alloc(W, H)
+                c0 = m.context(0)
+                for delivery in (V.DELIVER_PEER_STORE, V.DELIVER_GATHER):
+                    for tile_rows in (8, 5):
+                        c0.device_write(d_rgba, np.zeros(W * H, np.uint32), m.stream())
+                        for _ in range(3):   # back to back: the next frame's traces must wait for the previous frame's consumers
+                            m.dispatch(W, H, tile_rows, g["mode"], delivery, d_rgba, d_id)
+                        rgba = c0.device_read(d_rgba, (H, W, 4), np.uint8, m.stream())
+                        idd = c0.device_read(d_id, (H, W, 2), np.int32, m.stream())
+                        assert "%016x" % V.fnv1a64(rgba) == g["rgba_fnv1a64"], (key, devices, delivery, tile_rows)
+                        assert "%016x" % V.fnv1a64(idd) == g["id_dist_fnv1a64"], (key, devices, delivery, tile_rows)
+                m.synchronize()
+                m.frame_free(d_rgba, d_id)
+            finally:
+                m.close()
+    with pytest.raises(V.VrtError):
+        V.Multi([0, 99])
+
+
 def test_feedback_tile_scheduling_never_changes_pixels(V, O, product_scenes):
     """vrt_set_tile_scheduling: launches that repeat a shape start their tiles in an order derived from measured tile
     times. Whatever that order is -- fresh, stale after the camera moved or the scene changed, re-derived on every

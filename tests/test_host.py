@@ -201,6 +201,34 @@ def _scene_graph_vox(rot_byte, translation, second_translation):
     return b"VOX " + struct.pack("<i", 150) + _chunk(b"MAIN", b"", body) + b"\0" * 12
 
 
+def test_vox_loader_survives_hostile_files(V, O):
+    """A scene graph that refers back to an ancestor must not overflow the host stack, and XYZI chunks that claim far more
+    voxels than they carry must not cost memory for what is not there (the reference does both)."""
+    import resource
+    pts = [(1, 2, 3, 7), (2, 2, 3, 9)]
+    model = _chunk(b"SIZE", struct.pack("<iii", 4, 4, 4)) + _chunk(b"XYZI", struct.pack("<i", len(pts)) + bytes(v for p in pts for v in p))
+    trn = lambda nid, child: _chunk(b"nTRN", struct.pack("<i", nid) + _vdict({}) + struct.pack("<iiii", child, -1, 0, 1) + _vdict({}))
+    # 0 -> group 1 -> {transform 2 -> shape 3, transform 4 -> group 1 (cycle)}
+    body = model + trn(0, 1) + _chunk(b"nGRP", struct.pack("<i", 1) + _vdict({}) + struct.pack("<iii", 2, 2, 4)) + trn(2, 3)
+    body += _chunk(b"nSHP", struct.pack("<i", 3) + _vdict({}) + struct.pack("<i", 1) + struct.pack("<i", 0) + _vdict({})) + trn(4, 1)
+    cyclic = b"VOX " + struct.pack("<i", 150) + _chunk(b"MAIN", b"", body)
+    w = V.World()
+    ok, n = w.load_vox_bytes(cyclic)
+    assert ok and w.texel_count() > 0       # the shape was placed (once per pass round the cycle until the depth cap drops the branch)
+    # 300 XYZI chunks of 8 bytes each that claim 9.9 M voxels: 12 GB if every claim were allocated
+    big = b"".join(_chunk(b"SIZE", struct.pack("<iii", 4, 4, 4)) + _chunk(b"XYZI", struct.pack("<i", 9_900_000) + bytes((1, 1, 1, 5)))
+                   for _ in range(300))
+    hostile = b"VOX " + struct.pack("<i", 150) + _chunk(b"MAIN", b"", big)
+    before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    # a node 0 that is a transform to a missing child: scene-graph mode, so the 3e9 implied zero voxels are never walked
+    w2 = V.World()
+    ok2, n2 = w2.load_vox_bytes(b"VOX " + struct.pack("<i", 150) + _chunk(b"MAIN", b"", big + trn(0, 99)))
+    after = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    assert (after - before) < 200 * 1024          # KiB: nowhere near 300 x 40 MB
+    assert n2 == 0 and w2.texel_count() == 0 and len(hostile) < 20000
+    w.close(); w2.close()
+
+
 @pytest.mark.parametrize("rot", [4, 2, 9, 17, 40, 98, 120, 1, 6, 24, 70])
 def test_vox_loader_scene_graph_matches_oracle(V, O, rot):
     data = _scene_graph_vox(rot, b"10 -7 5", b"-3 12 20")

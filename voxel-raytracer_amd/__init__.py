@@ -146,6 +146,32 @@ def hip_lib():
         L.vrt_device.argtypes = [C.c_void_p]
         L.vrt_set_variant.argtypes = [C.c_void_p, C.c_int]
         L.vrt_variant_available.argtypes = [C.c_int]
+        L.vrt_dispatch_tiles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vrt_device_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.vrt_device_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.vrt_device_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.vrt_device_write.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.vrt_ipc_export.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
+        L.vrt_ipc_open.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
+        L.vrt_ipc_close.argtypes = [C.c_void_p, C.c_void_p]
+        L.vrt_stream_write_flag.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.vrt_stream_wait_flag.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.vrt_create_multi.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+        L.vrt_destroy_multi.argtypes = [C.c_void_p]
+        L.vrt_multi_last_error.restype = C.c_char_p
+        L.vrt_multi_last_error.argtypes = [C.c_void_p]
+        L.vrt_multi_devices.argtypes = [C.c_void_p]
+        L.vrt_multi_context.restype = C.c_void_p
+        L.vrt_multi_context.argtypes = [C.c_void_p, C.c_int]
+        L.vrt_multi_upload_octree.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]
+        L.vrt_multi_set_camera.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.vrt_multi_set_params.argtypes = [C.c_void_p, C.POINTER(Params)]
+        L.vrt_multi_frame_alloc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        L.vrt_multi_frame_free.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vrt_multi_dispatch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.vrt_multi_synchronize.argtypes = [C.c_void_p]
+        L.vrt_multi_stream.restype = C.c_void_p
+        L.vrt_multi_stream.argtypes = [C.c_void_p]
         L.vrt_debug_set_full_split.argtypes = [C.c_void_p, C.c_int]
         L.vrt_debug_set_bounce.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.vrt_version.restype = C.c_char_p
@@ -365,9 +391,9 @@ class Context:
         self._L = L
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and not getattr(self, "borrowed", False):
             self._L.vrt_destroy(self._h)
-            self._h = None
+        self._h = None
 
     __del__ = close
 
@@ -420,6 +446,46 @@ class Context:
     def dispatch_shard(self, width, height, tile_rows, shard, n_shards, mode, d_rgba, d_id, stream=None):
         self._chk(self._L.vrt_dispatch_shard(self._h, width, height, tile_rows, shard, n_shards, mode, d_rgba, d_id,
                                              stream))
+
+    def dispatch_tiles(self, width, height, tile_rows, shard, n_shards, mode, d_frame_rgba, d_frame_id, stream=None):
+        """the shard's row tiles at their place in a FULL frame (local, peer or IPC-mapped device memory)"""
+        self._chk(self._L.vrt_dispatch_tiles(self._h, width, height, tile_rows, shard, n_shards, mode, d_frame_rgba, d_frame_id, stream))
+
+    def device_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self._L.vrt_device_alloc(self._h, nbytes, C.byref(p)))
+        return p.value
+
+    def device_free(self, ptr):
+        self._chk(self._L.vrt_device_free(self._h, ptr))
+
+    def device_read(self, ptr, shape, dtype, stream=None):
+        out = np.empty(shape, dtype)
+        self._chk(self._L.vrt_device_read(self._h, ptr, out.ctypes.data, out.nbytes, stream))
+        return out
+
+    def device_write(self, ptr, arr, stream=None):
+        a = np.ascontiguousarray(arr)
+        self._chk(self._L.vrt_device_write(self._h, ptr, a.ctypes.data, a.nbytes, stream))
+
+    def ipc_export(self, ptr):
+        h = C.create_string_buffer(64)
+        self._chk(self._L.vrt_ipc_export(self._h, ptr, h))
+        return h.raw
+
+    def ipc_open(self, handle):
+        p = C.c_void_p()
+        self._chk(self._L.vrt_ipc_open(self._h, bytes(handle), C.byref(p)))
+        return p.value
+
+    def ipc_close(self, ptr):
+        self._chk(self._L.vrt_ipc_close(self._h, ptr))
+
+    def stream_write_flag(self, d_flag, value, stream=None):
+        self._chk(self._L.vrt_stream_write_flag(self._h, d_flag, value, stream))
+
+    def stream_wait_flag(self, d_flag, value, stream=None):
+        self._chk(self._L.vrt_stream_wait_flag(self._h, d_flag, value, stream))
 
     def dispatch_timed(self, width, height, row_begin, row_end, mode, d_rgba, d_id, iters, stream=None):
         ms = (C.c_float * iters)()
@@ -532,6 +598,66 @@ class Context:
         out = np.zeros_like(x)
         self._chk(self._L.vrt_debug_math(self._h, op, x.ctypes.data, y.ctypes.data, out.ctypes.data, x.size))
         return out
+
+
+DELIVER_PEER_STORE, DELIVER_GATHER = 0, 1
+
+
+class Multi:
+    """vrt_multi: one context per device in this process, frames assembled on the first device (include/vrt.h)."""
+
+    def __init__(self, devices):
+        L = hip_lib()
+        self._L = L
+        ids = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        r = L.vrt_create_multi(len(devices), ids, C.byref(h))
+        if r != 0:
+            raise VrtError(f"vrt_create_multi failed ({r}): {L.vrt_multi_last_error(None).decode()}")
+        self._h = h
+        self.n = len(devices)
+
+    def close(self):
+        if self._h:
+            self._L.vrt_destroy_multi(self._h)
+            self._h = None
+
+    def _chk(self, r):
+        if r != 0:
+            raise VrtError(f"vrt_multi error {r}: {self._L.vrt_multi_last_error(self._h).decode()}")
+
+    def upload_octree(self, texels, tex_dim):
+        t = np.ascontiguousarray(texels, dtype=np.uint8)
+        self._chk(self._L.vrt_multi_upload_octree(self._h, t.ctypes.data if t.size else None, t.size, tex_dim))
+
+    def set_camera(self, inv_proj, inv_view, cam_pos):
+        ip, iv, cp = (np.ascontiguousarray(x, dtype=np.float32) for x in (inv_proj, inv_view, cam_pos))
+        self._chk(self._L.vrt_multi_set_camera(self._h, _fptr(ip), _fptr(iv), _fptr(cp)))
+
+    def frame_alloc(self, width, height):
+        a, b = C.c_void_p(), C.c_void_p()
+        self._chk(self._L.vrt_multi_frame_alloc(self._h, width, height, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def frame_free(self, d_rgba, d_id):
+        self._chk(self._L.vrt_multi_frame_free(self._h, d_rgba, d_id))
+
+    def dispatch(self, width, height, tile_rows, mode, delivery, d_rgba, d_id):
+        self._chk(self._L.vrt_multi_dispatch(self._h, width, height, tile_rows, mode, delivery, d_rgba, d_id))
+
+    def synchronize(self):
+        self._chk(self._L.vrt_multi_synchronize(self._h))
+
+    def stream(self):
+        return self._L.vrt_multi_stream(self._h)
+
+    def context(self, i):
+        """the i-th device's context as a (borrowed) Context: do not close() it"""
+        c = Context.__new__(Context)
+        c._L = self._L
+        c._h = C.c_void_p(self._L.vrt_multi_context(self._h, i))
+        c.borrowed = True
+        return c
 
 
 def make_views(views):

@@ -99,6 +99,8 @@ Dict vox_dict(Cursor &c) {  // ref :61-72
 struct Model {
     int32_t sx = 0, sy = 0, sz = 0;
     std::vector<uint8_t> xyzi;  // 4 bytes per voxel
+    size_t n_voxels = 0;            // voxels the XYZI chunk claims; those past xyzi.size() / 4 read as zero bytes
+    uint8_t byte(size_t i) const { return i < xyzi.size() ? xyzi[i] : (uint8_t)0; }
 };
 
 struct Node {
@@ -177,23 +179,31 @@ inline ColorRGBA palette_entry(const Scene &s, uint8_t color_index) {
 }
 
 // ref :121-211
-void walk(const Scene &s, int id, const M4 &xf, Octree *tree, const int origin[3], const Voxel &material) {
+// depth: a scene graph whose nTRN child or nGRP kid refers back to an ancestor would recurse until the host stack
+// overflows (the reference does); no real file nests deeper than a handful of levels
+constexpr int kMaxGraphDepth = 64;
+void walk(const Scene &s, int id, const M4 &xf, Octree *tree, const int origin[3], const Voxel &material, int depth = 0) {
+    if (depth > kMaxGraphDepth) {
+        std::cerr << "vox: scene graph deeper than " << kMaxGraphDepth << " levels (a cycle?): branch dropped" << std::endl;
+        return;
+    }
     std::map<int, Node>::const_iterator it = s.nodes.find(id);
     if (it == s.nodes.end()) return;
     const Node &n = it->second;
     switch (n.kind) {
         case Node::Transform:
-            walk(s, n.child, mul(mul(xf, translation(n.t)), rotation(n.rot)), tree, origin, material);
+            walk(s, n.child, mul(mul(xf, translation(n.t)), rotation(n.rot)), tree, origin, material, depth + 1);
             break;
         case Node::Group:
-            for (size_t i = 0; i < n.kids.size(); ++i) walk(s, n.kids[i], xf, tree, origin, material);
+            for (size_t i = 0; i < n.kids.size(); ++i) walk(s, n.kids[i], xf, tree, origin, material, depth + 1);
             break;
         case Node::Shape: {
             if (n.model < 0 || n.model >= (int)s.models.size()) return;
             const Model &m = s.models[(size_t)n.model];
             const float cx = (float)m.sx / 2.0f, cy = (float)m.sy / 2.0f, cz = (float)m.sz / 2.0f;
-            for (size_t i = 0; i + 3 < m.xyzi.size(); i += 4) {
-                const float lx = (float)m.xyzi[i] - cx, ly = (float)m.xyzi[i + 1] - cy, lz = (float)m.xyzi[i + 2] - cz;
+            for (size_t v = 0; v < m.n_voxels; ++v) {
+                const size_t i = v * 4;
+                const float lx = (float)m.byte(i) - cx, ly = (float)m.byte(i + 1) - cy, lz = (float)m.byte(i + 2) - cz;
                 float w[3];
                 for (int r = 0; r < 3; ++r)
                     w[r] = (xf.at(0, r) * lx + xf.at(1, r) * ly) + (xf.at(2, r) * lz + xf.at(3, r) * 1.0f);
@@ -204,7 +214,7 @@ void walk(const Scene &s, int id, const M4 &xf, Octree *tree, const int origin[3
                 if (!in_safe_box(fx, fy, fz)) continue;
                 IVector3 c;
                 c.x = fx; c.y = fy; c.z = fz;
-                octree_insert(tree, VoxelObjCreate(material, palette_entry(s, m.xyzi[i + 3]), c));
+                octree_insert(tree, VoxelObjCreate(material, palette_entry(s, m.byte(i + 3)), c));
             }
             break;
         }
@@ -244,7 +254,13 @@ void parse_chunks(Cursor &c, Scene &s) {
             }
             Model m;
             m.sx = last_size[0]; m.sy = last_size[1]; m.sz = last_size[2];
-            m.xyzi.assign((size_t)count * 4, 0);
+            // The reference callocs count * 4 bytes and freads what the file holds (src/voxReader.cpp:284-297): a chunk that
+            // claims more voxels than it carries leaves the rest zero. Only the bytes that exist are stored here -- the
+            // zeros are implied by n_voxels -- so a small file with many inflated counts cannot exhaust memory.
+            m.n_voxels = (size_t)count;
+            const long have = file_size - c.tell();
+            const size_t stored = have <= 0 ? 0 : ((size_t)count * 4 < (size_t)have ? (size_t)count * 4 : (size_t)have);
+            m.xyzi.assign(stored, 0);
             for (size_t i = 0; i < m.xyzi.size(); ++i) c.u8(m.xyzi[i]);
             s.models.push_back(m);
         } else if (!memcmp(id, "RGBA", 4)) {
@@ -340,13 +356,14 @@ bool vrt_load_vox_memory(const uint8_t *data, size_t len, Octree *tree, int offs
     if (s.nodes.empty()) {  // RAW mode, ref :382-408
         long count = 0;
         for (size_t mi = 0; mi < s.models.size(); ++mi) {
-            const std::vector<uint8_t> &v = s.models[mi].xyzi;
-            for (size_t i = 0; i + 3 < v.size(); i += 4) {
-                const int fx = offsetX + v[i], fy = offsetY + v[i + 2], fz = offsetZ + v[i + 1];
+            const Model &v = s.models[mi];
+            for (size_t k = 0; k < v.n_voxels; ++k) {
+                const size_t i = k * 4;
+                const int fx = offsetX + v.byte(i), fy = offsetY + v.byte(i + 2), fz = offsetZ + v.byte(i + 1);
                 if (!in_safe_box(fx, fy, fz)) continue;
                 IVector3 p;
                 p.x = fx; p.y = fy; p.z = fz;
-                octree_insert(tree, VoxelObjCreate(material, palette_entry(s, v[i + 3]), p));
+                octree_insert(tree, VoxelObjCreate(material, palette_entry(s, v.byte(i + 3)), p));
                 ++count;
             }
         }

@@ -147,6 +147,8 @@ struct vrt_ctx {
     // feedback scheduling of the default kernel (see SchedState)
     int sched_period = 16;                   // every n-th launch of a shape measures its tiles; 0 = off
     std::vector<SchedState> sched;
+    uint64_t sched_tick = 0;
+    bool order_lds_raised = false;            // tile_order_kernel's dynamic-LDS ceiling raised on THIS context's device
     const uint32_t *dbg_group_order = nullptr;  // vrt_debug_set_tile_order: caller-owned buffers instead of the scheduler's
     uint32_t *dbg_tile_cost = nullptr;
     bool dbg_sched = false;
@@ -173,13 +175,10 @@ template <int MODE, class TRAV, int TW, int BLOCK, int WPE, bool PERSIST = false
 hipError_t launch_one(const vrt::KArgs &a, const vrt::ViewSet &vs, int grid, size_t lds_bytes, hipStream_t s,
                       hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {  // grid.y = a.n_views
     void (*kernel)(const vrt::KArgs, const vrt::ViewSet) = &vrt::trace_kernel<MODE, TRAV, TW, BLOCK, WPE, PERSIST, SCHED>;
-    if (lds_bytes > 48 * 1024) {  // above the default dynamic-LDS ceiling: opt in (CDNA4 has 160 KiB per CU)
-        static bool raised = false;
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            if (e != hipSuccess) return e;
-            raised = true;
-        }
+    if (lds_bytes > 48 * 1024) {  // above the default dynamic-LDS ceiling: opt in (CDNA4 has 160 KiB per CU). The attribute
+        // belongs to the (function, device) pair, so it is set on every such launch (LDS-staging A/B variants only)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return e;
     }
     if (ev0 || ev1)   // either may be null: the two-kernel full path tracer times from the first kernel's start to the second one's end
         hipExtLaunchKernelGGL(kernel, dim3(grid, a.n_views), dim3(BLOCK), lds_bytes, s, ev0, ev1, 0, a, vs);
@@ -261,7 +260,7 @@ constexpr long kSchedMinDenoiseGroups = 256;    // two workgroups fit a CU: 1,02
 // recycled when there are kSchedMaxStates). nullptr when device memory for it cannot be had: the launch then runs plain.
 SchedState *sched_state(vrt_ctx *c, hipStream_t s, int width, int n_rows, int row0, int row_stride, int tile_rows, int mode,
                         uint32_t n_tiles, uint32_t n_groups) {
-    static uint64_t tick = 0;
+    uint64_t &tick = c->sched_tick;
     ++tick;
     for (SchedState &st : c->sched)
         if (st.stream == s && st.width == width && st.n_rows == n_rows && st.row0 == row0 && st.row_stride == row_stride &&
@@ -316,7 +315,7 @@ bool camera_jumped(const float was[6], const float now[6]) {
 
 // After a measuring launch, on the same stream: reads that launch's ticks, rewrites the order the next launches read.
 int launch_order_kernel(vrt_ctx *c, SchedState *st, hipStream_t s) {
-    static bool raised = false;
+    bool &raised = c->order_lds_raised;   // per context, i.e. per device: the attribute does not carry over to another one
     const size_t lds = (size_t)st->n_groups * sizeof(uint32_t);
     if (lds > 48 * 1024 && !raised) {
         VRT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&vrt::tile_order_kernel),
@@ -607,6 +606,34 @@ int vrt_create(int device_id, vrt_ctx **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
     vrt_default_params(&c->params);
+    {   // the kernels re-read part of their arguments from the kernarg segment (late_args / late_view): check the layout
+        // they assume on this device before anything depends on it
+        vrt::KArgs a;
+        vrt::ViewSet vs;
+        std::memset(&a, 0, sizeof a);
+        std::memset(&vs, 0, sizeof vs);
+        a.n_views = vrt::kMaxViews; a.width = 0x1234; a.height = 0x2345; a.tex_dim = 77; a.compact = 1; a.voxel_scale = 0.75f;
+        a.light_dir[2] = 0.5f; a.highlighted[1] = -9;
+        for (int i = 0; i < vrt::kMaxViews; ++i) {
+            vs.v[i].out_rgba = (uint32_t *)(uintptr_t)(0x1000u + 16u * (unsigned)i);
+            vs.v[i].out_id = (int2 *)(uintptr_t)(0x2000u + 16u * (unsigned)i);
+            vs.v[i].cam_pos[1] = 3.0f + (float)i;
+        }
+        uint32_t *d_bad = nullptr, bad = 1;
+        if ((e = hipMalloc((void **)&d_bad, sizeof bad)) == hipSuccess && (e = hipMemsetAsync(d_bad, 0, sizeof bad, c->stream)) == hipSuccess) {
+            hipLaunchKernelGGL(vrt::kernarg_probe_kernel, dim3(1, vrt::kMaxViews), dim3(64), 0, c->stream, a, vs, d_bad);
+            if ((e = hipGetLastError()) == hipSuccess && (e = hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, c->stream)) == hipSuccess)
+                e = hipStreamSynchronize(c->stream);
+        }
+        (void)hipFree(d_bad);
+        if (e != hipSuccess || bad != 0) {
+            g_create_error = e != hipSuccess ? std::string("vrt_create: kernarg probe: ") + hipGetErrorString(e)
+                                             : "vrt_create: the kernarg segment is not laid out as late_args()/late_view() assume";
+            (void)hipStreamDestroy(c->stream);
+            delete c;
+            return e != hipSuccess ? VRT_E_NO_DEVICE : VRT_E_HIP;
+        }
+    }
     *out = c;
     return VRT_OK;
 }
@@ -665,11 +692,11 @@ int vrt_upload_octree(vrt_ctx *c, const uint8_t *texels, size_t used_bytes, uint
     VRT_HIP(c, hipSetDevice(c->device));
     const size_t bytes = lay.records.size() * sizeof(vrt::Record);
     if (bytes > c->nodes_capacity) {
-        VRT_HIP(c, hipStreamSynchronize(c->stream));
-        if (c->d_nodes) VRT_HIP(c, hipFree(c->d_nodes));
-        c->d_nodes = nullptr;
-        c->nodes_capacity = 0;
-        VRT_HIP(c, hipMalloc((void **)&c->d_nodes, bytes));
+        VRT_HIP(c, hipDeviceSynchronize());   // dispatches still reading the old array, on whatever stream
+        uint2 *fresh = nullptr;
+        VRT_HIP(c, hipMalloc((void **)&fresh, bytes));   // before the old array goes: a failure leaves the context as it was
+        if (c->d_nodes) (void)hipFree(c->d_nodes);
+        c->d_nodes = fresh;
         c->nodes_capacity = bytes;
     }
     // after every dispatch still reading the old tree, on whatever stream the caller enqueued it (uploads are rare:
@@ -730,11 +757,11 @@ int vrt_upload_records(vrt_ctx *c, const uint32_t *records, size_t n_records, ui
     VRT_HIP(c, hipSetDevice(c->device));
     const size_t bytes = n_records * sizeof(vrt::Record);
     if (bytes > c->nodes_capacity) {
-        VRT_HIP(c, hipStreamSynchronize(c->stream));
-        if (c->d_nodes) VRT_HIP(c, hipFree(c->d_nodes));
-        c->d_nodes = nullptr;
-        c->nodes_capacity = 0;
-        VRT_HIP(c, hipMalloc((void **)&c->d_nodes, bytes));
+        VRT_HIP(c, hipDeviceSynchronize());   // dispatches still reading the old array, on whatever stream
+        uint2 *fresh = nullptr;
+        VRT_HIP(c, hipMalloc((void **)&fresh, bytes));   // before the old array goes: a failure leaves the context as it was
+        if (c->d_nodes) (void)hipFree(c->d_nodes);
+        c->d_nodes = fresh;
         c->nodes_capacity = bytes;
     }
     VRT_HIP(c, hipDeviceSynchronize());  // see vrt_upload_octree
@@ -874,11 +901,14 @@ int vrt_patch_apply(vrt_ctx *c, const vrt_patch *patch, const uint32_t *subtree_
     // device copies, after every dispatch that may still read the old structures
     VRT_HIP(c, hipDeviceSynchronize());
     const size_t rec_bytes = c->host_records.size() * sizeof(vrt::Record);
+    // From here on the host structures are ahead of the device copies: a failure must not leave a context that would
+    // dispatch over half-updated (or freed) device arrays, so it drops the scene (the caller uploads again).
+    struct Guard { vrt_ctx *c; bool armed = true; ~Guard() { if (armed) { c->have_scene = false; c->analysis_valid = false; } } } guard{c};
     if (rec_bytes > c->nodes_capacity) {
-        if (c->d_nodes) VRT_HIP(c, hipFree(c->d_nodes));
-        c->d_nodes = nullptr;
-        c->nodes_capacity = 0;
-        VRT_HIP(c, hipMalloc((void **)&c->d_nodes, rec_bytes * 2));
+        uint2 *fresh = nullptr;
+        VRT_HIP(c, hipMalloc((void **)&fresh, rec_bytes * 2));   // before the old array goes
+        if (c->d_nodes) (void)hipFree(c->d_nodes);
+        c->d_nodes = fresh;
         c->nodes_capacity = rec_bytes * 2;
         VRT_HIP(c, hipMemcpy(c->d_nodes, c->host_records.data(), rec_bytes, hipMemcpyHostToDevice));
     } else {
@@ -906,12 +936,10 @@ int vrt_patch_apply(vrt_ctx *c, const vrt_patch *patch, const uint32_t *subtree_
                 if (!rr && site.root_index >= 0) rr = upload_roots(c);
                 if (!rr && rg.cell_repointed) rr = upload_cells(c, (size_t)site.parent_node * 64 + site.parent_cell, 1);
             }
-            if (rr) {   // the host structures are ahead of the device copies: force a full re-derivation before the next dispatch
-                c->analysis_valid = false;
-                return rr;
-            }
+            if (rr) return rr;   // the guard drops the scene
         }
     }
+    guard.armed = false;
     return VRT_OK;
 }
 
@@ -1003,6 +1031,18 @@ int vrt_dispatch_shard(vrt_ctx *c, int width, int height, int tile_rows, int sha
                    d_id_dist, stream ? (hipStream_t)stream : c->stream);
 }
 
+int vrt_dispatch_tiles(vrt_ctx *c, int width, int height, int tile_rows, int shard, int n_shards, int mode, void *d_frame_rgba8,
+                       void *d_frame_id_dist, void *stream) {
+    int r = check_frame(c, width, height);
+    if (r) return r;
+    const int rows = vrt_shard_rows(height, tile_rows, shard, n_shards);
+    if (rows < 0) return fail(c, VRT_E_INVALID, "vrt_dispatch_tiles: bad tile_rows/shard/n_shards");
+    VRT_HIP(c, hipSetDevice(c->device));
+    // the shard's tiles at their frame rows (compact = 0): the frame may be local, a peer's, or an IPC mapping
+    return enqueue(c, width, height, shard * tile_rows, rows, tile_rows, tile_rows * n_shards, 0, mode, d_frame_rgba8, d_frame_id_dist,
+                   stream ? (hipStream_t)stream : c->stream);
+}
+
 int vrt_dispatch_views(vrt_ctx *c, int width, int height, int tile_rows, int shard, int n_shards, int mode,
                        const vrt_view *views, int n_views, void *stream) {
     int r = check_frame(c, width, height);
@@ -1039,19 +1079,22 @@ int vrt_dispatch_timed(vrt_ctx *c, int width, int height, int row_begin, int row
     if (row_begin < 0 || row_end > height || row_begin >= row_end) return fail(c, VRT_E_INVALID, "vrt_dispatch_timed: bad row range");
     VRT_HIP(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    std::vector<hipEvent_t> ev((size_t)iters * 2);
-    for (auto &e : ev) VRT_HIP(c, hipEventCreate(&e));
+    std::vector<hipEvent_t> ev((size_t)iters * 2, nullptr);
     int rc = VRT_OK;
+    hipError_t he = hipSuccess;
+    for (auto &e : ev)
+        if (he == hipSuccess) he = hipEventCreate(&e);
     const int n = row_end - row_begin;
-    for (int i = 0; i < iters && rc == VRT_OK; ++i) {
-        VRT_HIP(c, hipEventRecord(ev[2 * i], s));
-        rc = enqueue(c, width, height, row_begin, n, n, 0, 0, mode, d_rgba8, d_id_dist, s);
-        VRT_HIP(c, hipEventRecord(ev[2 * i + 1], s));
+    for (int i = 0; i < iters && rc == VRT_OK && he == hipSuccess; ++i) {
+        he = hipEventRecord(ev[2 * i], s);
+        if (he == hipSuccess) rc = enqueue(c, width, height, row_begin, n, n, 0, 0, mode, d_rgba8, d_id_dist, s);
+        if (he == hipSuccess && rc == VRT_OK) he = hipEventRecord(ev[2 * i + 1], s);
     }
-    VRT_HIP(c, hipStreamSynchronize(s));
-    if (rc == VRT_OK)
-        for (int i = 0; i < iters; ++i) VRT_HIP(c, hipEventElapsedTime(&ms_out[i], ev[2 * i], ev[2 * i + 1]));
-    for (auto &e : ev) (void)hipEventDestroy(e);
+    if (he == hipSuccess) he = hipStreamSynchronize(s);
+    for (int i = 0; i < iters && rc == VRT_OK && he == hipSuccess; ++i) he = hipEventElapsedTime(&ms_out[i], ev[2 * i], ev[2 * i + 1]);
+    for (auto &e : ev)
+        if (e) (void)hipEventDestroy(e);   // on every path
+    if (rc == VRT_OK && he != hipSuccess) rc = fail(c, VRT_E_HIP, std::string("vrt_dispatch_timed: ") + hipGetErrorString(he));
     return rc;
 }
 
@@ -1237,6 +1280,7 @@ int vrt_debug_math(vrt_ctx *c, int op, const float *x, const float *y, float *ou
     VRT_HIP(c, hipSetDevice(c->device));
     float *dx = nullptr, *dy = nullptr, *dout = nullptr;
     const size_t bytes = (size_t)n * sizeof(float);
+    struct Free { float *&a, *&b, *&o; ~Free() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(o); } } free_on_exit{dx, dy, dout};
     VRT_HIP(c, hipMalloc((void **)&dx, bytes));
     VRT_HIP(c, hipMalloc((void **)&dy, bytes));
     VRT_HIP(c, hipMalloc((void **)&dout, bytes));
@@ -1249,7 +1293,6 @@ int vrt_debug_math(vrt_ctx *c, int op, const float *x, const float *y, float *ou
     VRT_HIP(c, hipGetLastError());
     VRT_HIP(c, hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, c->stream));
     VRT_HIP(c, hipStreamSynchronize(c->stream));
-    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
     return VRT_OK;
 }
 

@@ -496,6 +496,23 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint4 *group_tic
     for (uint32_t g = t; g < n_groups; g += 1024) group_order[atomicAdd(&hist[group_cost[g] >> shift], 1u)] = g;
 }
 
+// late_args() / late_view() assume the kernarg segment holds KArgs at offset 0 and ViewSet behind it at its natural
+// alignment. The compiler's layout rules guarantee that for two by-value aggregates, and these keep it from drifting:
+static_assert(__is_trivially_copyable(KArgs) && __is_trivially_copyable(ViewSet), "kernel arguments are copied bytewise");
+static_assert(alignof(KArgs) <= 8 && alignof(ViewSet) <= 8, "by-value kernel arguments are laid out at their natural alignment (<= 8 here)");
+// ... and this probe checks it on the device once per context (vrt_create): every view's late pointers and a few late
+// uniforms against the by-value arguments. out[0] = number of mismatches.
+__global__ void kernarg_probe_kernel(const KArgs a, const ViewSet vs, uint32_t *out) {
+    const LateArgs la = late_args();
+    const LateView lv = late_view();
+    const View &v = vs.v[blockIdx.y];
+    uint32_t bad = 0;
+    bad += la->width != a.width || la->height != a.height || la->tex_dim != a.tex_dim || la->compact != a.compact;
+    bad += la->light_dir[2] != a.light_dir[2] || la->highlighted[1] != a.highlighted[1] || la->voxel_scale != a.voxel_scale;
+    bad += lv->out_rgba != v.out_rgba || lv->out_id != v.out_id || lv->cam_pos[1] != v.cam_pos[1];
+    if (threadIdx.x == 0 && bad) atomicAdd(out, bad);
+}
+
 // exactness probe for the arithmetic contract: out[i] = op(x[i], y[i])
 __global__ void math_probe_kernel(int op, const float *x, const float *y, float *out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -207,3 +207,137 @@ class FramePipeline:
 
     def frame_views(self):
         return self.plan.frame_views(self.store)
+
+
+class PeerFramePipeline:
+    """Every frame delivered with NO collective: the ranks' trace kernels store their row tiles straight into a frame
+    buffer that lives on the frame's root rank, through an IPC mapping of that buffer (xGMI peer stores; include/vrt.h
+    vrt_dispatch_tiles / vrt_ipc_*). Ordering is by stream-ordered flags in the root's memory, no host in the loop. A root
+    owns n_buf frame buffers ("slots"); the i-th frame of a root uses slot k = i % n_buf and, on every rank, HIP stream k
+    (so the drain of one launch overlaps the start of the next ones, and a slot's frames stay ordered):
+
+        arrived[root][r][k]  rank r's stream k writes i + 1 after its tiles of the root's i-th frame
+        consumed[root][k]    the root's consumer stream writes i + 1 once it has seen every rank's `arrived` of frame i; a
+                             rank waits for consumed[k] >= i - n_buf + 1 before it overwrites slot k with frame i
+
+    rotate=False: rank 0 is the root of every frame (a single display head: all 12 B/pixel cross rank 0's links).
+    rotate=True : frame f is assembled on rank f % world (a consumer per GPU -- encoder, display pass -- takes every
+                  world-th frame): the inbound traffic spreads over all GPUs' links.
+    The control plane (exchange of the IPC handles) runs over the process group once, at construction.
+    """
+
+    def __init__(self, ctx, plan, n_buf=4, rotate=False, group=None):
+        import numpy as np
+        self.ctx, self.plan, self.n_buf, self.rotate, self.group = ctx, plan, n_buf, rotate, group
+        W, H, world, rank = plan.width, plan.height, plan.world, plan.rank
+        self.roots = list(range(world)) if rotate else [0]
+        self.own = rank in self.roots
+        self.np = np
+        self.n_flags = (world + 1) * n_buf          # 64 bytes apart
+        self.local = None
+        mine = None
+        if self.own:
+            self.local = {"rgba": [ctx.device_alloc(W * H * 4) for _ in range(n_buf)],
+                          "id": [ctx.device_alloc(W * H * 8) for _ in range(n_buf)],
+                          "flags": ctx.device_alloc(64 * self.n_flags)}
+            mine = {"rgba": [ctx.ipc_export(p) for p in self.local["rgba"]], "id": [ctx.ipc_export(p) for p in self.local["id"]],
+                    "flags": ctx.ipc_export(self.local["flags"])}
+        gathered = [None] * world
+        if world > 1:
+            dist.all_gather_object(gathered, mine, group=group)
+        else:
+            gathered = [mine]
+        self.maps = {}
+        for root in self.roots:
+            if root == rank:
+                self.maps[root] = self.local
+            else:
+                h = gathered[root]
+                self.maps[root] = {"rgba": [ctx.ipc_open(x) for x in h["rgba"]], "id": [ctx.ipc_open(x) for x in h["id"]],
+                                   "flags": ctx.ipc_open(h["flags"])}
+        self.frame = 0
+        self.seen = {root: 0 for root in self.roots}   # frames of each root enqueued so far
+        self.streams = [torch.cuda.Stream() for _ in range(n_buf)]
+        self.consumer = torch.cuda.Stream() if self.own else None
+
+    def _arrived(self, root, r, k):
+        return self.maps[root]["flags"] + 64 * (r * self.n_buf + k)
+
+    def _consumed(self, root, k):
+        return self.maps[root]["flags"] + 64 * (self.plan.world * self.n_buf + k)
+
+    def rehearse(self, timeout_s=10.0):
+        """One flag hand-shake per (rank, root) pair with HOST-side polling only (nothing can hang): every rank writes
+        an arrival flag through the mapping, every root checks that the value shows up in its own memory. Returns the
+        reason as text when the mappings do not behave, else None."""
+        import time
+        world, rank = self.plan.world, self.plan.rank
+        for root in self.roots:
+            self.ctx.stream_write_flag(self._arrived(root, rank, 0), 0x7000 + rank, self.streams[0].cuda_stream)
+        self.streams[0].synchronize()
+        if world > 1:
+            dist.barrier(group=self.group)
+        bad = None
+        if self.own:
+            t0 = time.time()
+            want = [0x7000 + r for r in range(world)]
+            while True:
+                got = [int(self.ctx.device_read(self.local["flags"] + 64 * r * self.n_buf, (1,), self.np.uint32)[0]) for r in range(world)]
+                if got == want:
+                    break
+                if time.time() - t0 > timeout_s:
+                    bad = f"rank {rank}: arrival flags {got} != {want} after {timeout_s} s"
+                    break
+                time.sleep(0.01)
+            self.ctx.device_write(self.local["flags"], self.np.zeros(16 * self.n_flags, self.np.uint32))
+        out = [None] * world
+        if world > 1:
+            dist.all_gather_object(out, bad, group=self.group)
+        else:
+            out = [bad]
+        return next((b for b in out if b), None)
+
+    def step(self, dispatch_tiles):
+        """enqueue frame self.frame: dispatch_tiles(d_rgba, d_id, stream) must trace this rank's tiles on that stream"""
+        f, world, rank = self.frame, self.plan.world, self.plan.rank
+        root = f % world if self.rotate else 0
+        i = self.seen[root]                  # index of this frame among the root's frames
+        k = i % self.n_buf
+        stream = self.streams[k].cuda_stream
+        if i >= self.n_buf:                  # the slot's previous frame must have been consumed
+            self.ctx.stream_wait_flag(self._consumed(root, k), i - self.n_buf + 1, stream)
+        if self.plan.rows_local:
+            dispatch_tiles(self.maps[root]["rgba"][k], self.maps[root]["id"][k], stream)
+        self.ctx.stream_write_flag(self._arrived(root, rank, k), i + 1, stream)
+        if root == rank:                     # this rank's consumer: frame complete once every rank has arrived
+            cs = self.consumer.cuda_stream
+            for r in range(world):
+                self.ctx.stream_wait_flag(self._arrived(root, r, k), i + 1, cs)
+            self.ctx.stream_write_flag(self._consumed(root, k), i + 1, cs)
+        self.seen[root] = i + 1
+        self.frame += 1
+
+    def drain(self):
+        for st in self.streams:
+            st.synchronize()
+        if self.consumer is not None:
+            self.consumer.synchronize()
+
+    def last_frame(self):
+        """(rgba [H, W, 4] uint8, id [H, W, 2] int32) of the newest frame assembled on THIS rank (None if it roots none)"""
+        if not self.own or self.seen.get(self.plan.rank, 0) == 0:
+            return None
+        H, W = self.plan.height, self.plan.width
+        k = (self.seen[self.plan.rank] - 1) % self.n_buf
+        return (self.ctx.device_read(self.local["rgba"][k], (H, W, 4), self.np.uint8),
+                self.ctx.device_read(self.local["id"][k], (H, W, 2), self.np.int32))
+
+    def close(self):
+        for root, m in self.maps.items():
+            if root != self.plan.rank:
+                for p in m["rgba"] + m["id"] + [m["flags"]]:
+                    self.ctx.ipc_close(p)
+        if self.local:
+            for p in self.local["rgba"] + self.local["id"] + [self.local["flags"]]:
+                self.ctx.device_free(p)
+        self.maps, self.local = {}, None
