@@ -117,6 +117,19 @@ int vrt_set_camera(vrt_ctx *ctx, const float inv_projection[16], const float inv
  * Either pointer may be NULL. Any width/height >= 1 is accepted. */
 int vrt_dispatch(vrt_ctx *ctx, int width, int height, int mode, uint8_t *out_rgba8, int32_t *out_id_dist);
 
+/* The same, asynchronous and double-buffered: the call enqueues the trace and the two copies to the host on one of two
+ * internal lanes (a stream and a pair of device images each) and returns a ticket (0 or 1); vrt_dispatch_wait(ticket)
+ * blocks until that frame's host buffers are complete. While frame i crosses PCIe, frame i+1 is traced: a loop that
+ * keeps two frames in flight runs at the copy's rate (12 B/pixel over PCIe: 24.9 MB, >= 0.40 ms at the link's 63 GB/s
+ * for a 1080p frame -- no arrangement of copies brings both images of that frame to the host faster) instead of trace +
+ * copy. The host buffers should be pinned (vrt_host_alloc): into pageable memory the runtime stages the copy and the
+ * call blocks for most of it. At most two frames in flight: a third call waits for the older ticket itself. */
+int vrt_dispatch_async(vrt_ctx *ctx, int width, int height, int mode, uint8_t *out_rgba8, int32_t *out_id_dist, int *ticket);
+int vrt_dispatch_wait(vrt_ctx *ctx, int ticket);
+/* page-locked host memory for those buffers (hipHostMalloc / hipHostFree) */
+int vrt_host_alloc(vrt_ctx *ctx, size_t bytes, void **host_ptr);
+int vrt_host_free(vrt_ctx *ctx, void *host_ptr);
+
 /* Stream-ordered dispatch into DEVICE buffers laid out as full frames; only
  * rows [row_begin, row_end) are traced and written (row sharding across GPUs).
  * stream: a hipStream_t, or NULL for the context's own stream. Returns after

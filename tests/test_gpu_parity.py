@@ -516,6 +516,44 @@ def test_row_sharding_properties_at_full_size(ctx, V, golden, product_scenes):
     assert np.array_equal(again_rgba, full_rgba) and np.array_equal(again_id, full_id)
 
 
+def test_async_host_dispatch_into_pinned_buffers(ctx, V, golden, product_scenes):
+    """vrt_dispatch_async / vrt_dispatch_wait: two frames in flight, page-locked host buffers, tickets; frames of different
+    cameras must not mix, a third call must wait for the oldest ticket by itself, pageable buffers work too."""
+    g = golden["frames"]["frames"]["dragon_256x144/mode1"]
+    tex, dim = product_scenes["dragon"]
+    W, H = g["width"], g["height"]
+    cam_a = _setup(ctx, V, tex, dim, g["pose"], W, H)
+    want_a = ctx.dispatch(W, H, 1)
+    pose_b = (60.3, 70.7, 120.2, -80.0, -15.0)
+    cam_b = V.camera_block(pose_b[:3], pose_b[3], pose_b[4], W, H)[:3]
+    ctx.set_camera(*cam_b)
+    want_b = ctx.dispatch(W, H, 1)
+    assert "%016x" % V.fnv1a64(want_a[0]) == g["rgba_fnv1a64"] and not np.array_equal(want_a[0], want_b[0])
+    bufs = [(ctx.host_alloc((H, W, 4), np.uint8), ctx.host_alloc((H, W, 2), np.int32)) for _ in range(2)]
+    try:
+        for rep in range(5):   # A into lane 0, B into lane 1, alternating; the third call reuses lane 0 and must wait for it
+            ctx.set_camera(*cam_a)
+            t0 = ctx.dispatch_async(W, H, 1, *bufs[0])
+            ctx.set_camera(*cam_b)
+            t1 = ctx.dispatch_async(W, H, 1, *bufs[1])
+            assert {t0, t1} == {0, 1}
+            ctx.dispatch_wait(t0)
+            _assert_same(bufs[0][0], want_a[0], "async lane A rgba8")
+            _assert_same(bufs[0][1], want_a[1], "async lane A id/dist")
+            ctx.dispatch_wait(t1)
+            _assert_same(bufs[1][0], want_b[0], "async lane B rgba8")
+            _assert_same(bufs[1][1], want_b[1], "async lane B id/dist")
+        pageable = np.zeros((H, W, 4), np.uint8)
+        t = ctx.dispatch_async(W, H, 1, pageable, None)
+        ctx.dispatch_wait(t)
+        ctx.dispatch_wait(t)   # idempotent
+        _assert_same(pageable, want_b[0], "async into pageable memory")
+    finally:
+        for a_, b_ in bufs:
+            ctx.host_free(a_)
+            ctx.host_free(b_)
+
+
 def test_tiles_into_one_frame_ipc_and_flags(ctx, V, golden, product_scenes):
     """vrt_dispatch_tiles: the shards of a frame written at their place in ONE full frame (what a peer GPU does through an
     xGMI mapping); device memory exported to another process and stored into from there (the one-process-per-GPU form:

@@ -42,5 +42,30 @@ def main():
         print("%-42s %8.3f ms per call" % (name, (time.perf_counter() - t0) / n * 1e3))
 
 
+    # the asynchronous, double-buffered form into page-locked buffers: two frames in flight
+    for both in (True, False):
+        bufs = [(ctx.host_alloc((H, W, 4), np.uint8), ctx.host_alloc((H, W, 2), np.int32) if both else None) for _ in range(2)]
+        for mode, label in ((0, "primary"), (2, "full")):
+            tickets = []
+            for i in range(4):
+                tickets.append(ctx.dispatch_async(W, H, mode, *bufs[i & 1]))
+            for t in set(tickets):
+                ctx.dispatch_wait(t)
+            n = 40
+            t0 = time.perf_counter()
+            for i in range(n):
+                ctx.dispatch_async(W, H, mode, *bufs[i & 1])
+            ctx.dispatch_wait(0)
+            ctx.dispatch_wait(1)
+            dt = (time.perf_counter() - t0) / n
+            ok = np.array_equal(bufs[0][0], bufs[1][0]) and (not both or np.array_equal(bufs[0][1], bufs[1][1]))
+            print("%-58s %8.3f ms per frame  (both lanes hold the same frame: %s)" %
+                  (f"vrt_dispatch_async {label} -> pinned rgba" + (" + id/dist" if both else " only"), dt * 1e3, ok))
+        for a, b in bufs:
+            ctx.host_free(a)
+            if b is not None:
+                ctx.host_free(b)
+
+
 if __name__ == "__main__":
     main()

@@ -146,6 +146,10 @@ def hip_lib():
         L.vrt_device.argtypes = [C.c_void_p]
         L.vrt_set_variant.argtypes = [C.c_void_p, C.c_int]
         L.vrt_variant_available.argtypes = [C.c_int]
+        L.vrt_dispatch_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.vrt_dispatch_wait.argtypes = [C.c_void_p, C.c_int]
+        L.vrt_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.vrt_host_free.argtypes = [C.c_void_p, C.c_void_p]
         L.vrt_dispatch_tiles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vrt_device_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.vrt_device_free.argtypes = [C.c_void_p, C.c_void_p]
@@ -446,6 +450,26 @@ class Context:
     def dispatch_shard(self, width, height, tile_rows, shard, n_shards, mode, d_rgba, d_id, stream=None):
         self._chk(self._L.vrt_dispatch_shard(self._h, width, height, tile_rows, shard, n_shards, mode, d_rgba, d_id,
                                              stream))
+
+    def host_alloc(self, shape, dtype):
+        """a page-locked numpy array (vrt_host_alloc); release with host_free(arr)"""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._chk(self._L.vrt_host_alloc(self._h, n, C.byref(p)))
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n,)).view(dtype).reshape(shape)
+        return arr
+
+    def host_free(self, arr):
+        self._chk(self._L.vrt_host_free(self._h, arr.ctypes.data))
+
+    def dispatch_async(self, width, height, mode, out_rgba, out_id):
+        t = C.c_int(-1)
+        self._chk(self._L.vrt_dispatch_async(self._h, width, height, mode, out_rgba.ctypes.data if out_rgba is not None else None,
+                                             out_id.ctypes.data if out_id is not None else None, C.byref(t)))
+        return t.value
+
+    def dispatch_wait(self, ticket):
+        self._chk(self._L.vrt_dispatch_wait(self._h, ticket))
 
     def dispatch_tiles(self, width, height, tile_rows, shard, n_shards, mode, d_frame_rgba, d_frame_id, stream=None):
         """the shard's row tiles at their place in a FULL frame (local, peer or IPC-mapped device memory)"""

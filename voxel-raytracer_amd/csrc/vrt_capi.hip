@@ -113,6 +113,16 @@ struct vrt_ctx {
     void *d_id = nullptr;
     void *d_shown = nullptr;
     size_t scratch_pixels = 0;
+    // vrt_dispatch_async: two lanes, each a stream + device images + "the copies have landed" event
+    struct AsyncLane {
+        hipStream_t stream = nullptr;
+        void *d_rgba = nullptr, *d_id = nullptr;
+        size_t pixels = 0;
+        hipEvent_t done = nullptr;
+        bool busy = false;
+    };
+    AsyncLane lane[2];
+    int next_lane = 0;
     // optional per-launch hipEvent pairs (vrt_set_profiling)
     bool profiling = false;
     std::vector<hipEvent_t> prof_events;  // 2 per slot
@@ -657,6 +667,12 @@ void vrt_destroy(vrt_ctx *c) {
         (void)hipFree(st.d_cost);
         (void)hipFree(st.d_order);
     }
+    for (auto &ln : c->lane) {
+        if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
+        (void)hipFree(ln.d_rgba);
+        (void)hipFree(ln.d_id);
+        if (ln.done) (void)hipEventDestroy(ln.done);
+    }
     for (auto &e : c->prof_events) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1068,6 +1084,63 @@ int vrt_dispatch(vrt_ctx *c, int width, int height, int mode, uint8_t *out_rgba8
     if (out_rgba8) VRT_HIP(c, hipMemcpyAsync(out_rgba8, c->d_rgba, px * 4, hipMemcpyDeviceToHost, c->stream));
     if (out_id_dist) VRT_HIP(c, hipMemcpyAsync(out_id_dist, c->d_id, px * 8, hipMemcpyDeviceToHost, c->stream));
     VRT_HIP(c, hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+
+int vrt_dispatch_wait(vrt_ctx *c, int ticket) {
+    if (!c || ticket < 0 || ticket > 1) return c ? fail(c, VRT_E_INVALID, "vrt_dispatch_wait: ticket") : VRT_E_INVALID;
+    vrt_ctx::AsyncLane &ln = c->lane[ticket];
+    if (!ln.busy) return VRT_OK;
+    VRT_HIP(c, hipSetDevice(c->device));
+    VRT_HIP(c, hipEventSynchronize(ln.done));
+    ln.busy = false;
+    return VRT_OK;
+}
+
+int vrt_dispatch_async(vrt_ctx *c, int width, int height, int mode, uint8_t *out_rgba8, int32_t *out_id_dist, int *ticket) {
+    int r = check_frame(c, width, height);
+    if (r) return r;
+    if (!ticket) return fail(c, VRT_E_INVALID, "vrt_dispatch_async: null ticket");
+    VRT_HIP(c, hipSetDevice(c->device));
+    const int k = c->next_lane;
+    vrt_ctx::AsyncLane &ln = c->lane[k];
+    r = vrt_dispatch_wait(c, k);   // at most two frames in flight
+    if (r) return r;
+    const size_t px = (size_t)width * (size_t)height;
+    if (!ln.stream) {
+        VRT_HIP(c, hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+        VRT_HIP(c, hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+    }
+    if (px > ln.pixels) {
+        void *a = nullptr, *b = nullptr;
+        VRT_HIP(c, hipMalloc(&a, px * 4));
+        if (hipMalloc(&b, px * 8) != hipSuccess) { (void)hipFree(a); return fail(c, VRT_E_HIP, "vrt_dispatch_async: hipMalloc"); }
+        (void)hipFree(ln.d_rgba);
+        (void)hipFree(ln.d_id);
+        ln.d_rgba = a; ln.d_id = b; ln.pixels = px;
+    }
+    r = enqueue(c, width, height, 0, height, height, 0, 0, mode, out_rgba8 ? ln.d_rgba : nullptr, out_id_dist ? ln.d_id : nullptr, ln.stream);
+    if (r) return r;
+    if (out_rgba8) VRT_HIP(c, hipMemcpyAsync(out_rgba8, ln.d_rgba, px * 4, hipMemcpyDeviceToHost, ln.stream));
+    if (out_id_dist) VRT_HIP(c, hipMemcpyAsync(out_id_dist, ln.d_id, px * 8, hipMemcpyDeviceToHost, ln.stream));
+    VRT_HIP(c, hipEventRecord(ln.done, ln.stream));
+    ln.busy = true;
+    *ticket = k;
+    c->next_lane = k ^ 1;
+    return VRT_OK;
+}
+
+int vrt_host_alloc(vrt_ctx *c, size_t bytes, void **host_ptr) {
+    if (!c || !host_ptr || bytes == 0) return VRT_E_INVALID;
+    *host_ptr = nullptr;
+    VRT_HIP(c, hipSetDevice(c->device));
+    VRT_HIP(c, hipHostMalloc(host_ptr, bytes, hipHostMallocDefault));
+    return VRT_OK;
+}
+
+int vrt_host_free(vrt_ctx *c, void *host_ptr) {
+    if (!c) return VRT_E_INVALID;
+    if (host_ptr) VRT_HIP(c, hipHostFree(host_ptr));
     return VRT_OK;
 }
 
