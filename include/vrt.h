@@ -90,7 +90,8 @@ int vrt_get_scene_info(const vrt_ctx *ctx, vrt_scene_info *info);
  *   3. vrt_patch_apply() appends those records, rewrites A's record, rebuilds A's part of the wide layout and copies
  *      only what changed to the device (after waiting for dispatches in flight).
  * vrt_patch_plan returns VRT_E_STATE when no ancestor qualifies (use vrt_upload_octree / vrt_upload_records).
- * Replaced sub-trees stay allocated until the next full upload; vrt_get_scene_info().n_records grows accordingly.
+ * Replaced sub-trees stay allocated until they outweigh the tree, then vrt_patch_plan compacts the arrays (vrt_compact);
+ * vrt_get_scene_info().n_records shows both.
  * Pixels after a patch equal those after a full upload of the edited tree. */
 typedef struct vrt_patch {
     int32_t depth;       /* of A below the root, >= 1 */
@@ -98,6 +99,18 @@ typedef struct vrt_patch {
 } vrt_patch;
 int vrt_patch_plan(vrt_ctx *ctx, int x, int y, int z, int max_depth, vrt_patch *out);
 int vrt_patch_apply(vrt_ctx *ctx, const vrt_patch *patch, const uint32_t *subtree_records, size_t n_records);
+/* A batch of edits (a brush stroke, an explosion; src/main.cpp:843-914 re-flattens once per click): between
+ * vrt_patch_begin and vrt_patch_end, vrt_patch_plan / vrt_patch_apply work on the library's host copy of the structures
+ * only -- each plan sees the patches before it -- and vrt_patch_end sends everything the batch appended or rewrote to the
+ * device in one go (one wait for dispatches in flight, one upload). Dispatching with a batch open is an error
+ * (VRT_E_STATE). A patch the library refuses (VRT_E_STATE / VRT_E_MALFORMED) changes nothing; a device failure in
+ * vrt_patch_end drops the scene (upload again). Outside a batch vrt_patch_apply is begin + apply + end. */
+int vrt_patch_begin(vrt_ctx *ctx);
+int vrt_patch_end(vrt_ctx *ctx);
+/* Reclaims what patches left behind (replaced child blocks and wide nodes): the device arrays are re-laid from the live
+ * tree, without a texel stream. vrt_patch_plan does this by itself once the garbage outweighs the tree; pixels do not
+ * change. */
+int vrt_compact(vrt_ctx *ctx);
 
 /* EXTENSION (not a reference interface): upload the device record array itself -- 2 x uint32 per record,
  * level order, root first; internal: {child_mask | leaf_mask << 8, first child index}, leaf:

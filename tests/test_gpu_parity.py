@@ -1017,17 +1017,40 @@ def test_voxel_edits_patched_on_device_equal_full_uploads(V, O):
         for z in range(8):
             w2.insert(x, 0, z, 0xa0a0a0ff)
     a.upload_octree(*w2.flatten())
-    refused = 0
-    for step in range(4000):
-        x, y, z = (int(v) for v in rng.integers(0, 24, size=3))
-        if step % 3 == 2:
-            w2.remove(x, y, z)
-        else:
-            w2.insert(x, y, z, 0x50b43cff if step % 2 else 0xc8dcff50, 1.5 if step % 2 == 0 else 3.0, 0.0, 0.0)
-        if a.patch_voxel(w2, x, y, z) is None:
-            refused += 1
-            a.upload_octree(*w2.flatten())
-    assert refused >= 1
+    refused = batches = 0
+    peak = 0
+    step = 0
+    while step < 4000:
+        # every 7th round is a brush stroke: up to 12 edits between vrt_patch_begin and vrt_patch_end (one device update)
+        stroke = 12 if (step // 50) % 7 == 3 else 1
+        if stroke > 1:
+            a.patch_begin()
+            batches += 1
+        for _ in range(stroke):
+            x, y, z = (int(v) for v in rng.integers(0, 24, size=3))
+            if step % 3 == 2:
+                w2.remove(x, y, z)
+            else:
+                w2.insert(x, y, z, 0x50b43cff if step % 2 else 0xc8dcff50, 1.5 if step % 2 == 0 else 3.0, 0.0, 0.0)
+            step += 1
+            if a.patch_voxel(w2, x, y, z) is None:
+                refused += 1
+                if stroke > 1:
+                    a.patch_end()
+                a.upload_octree(*w2.flatten())
+                if stroke > 1:
+                    a.patch_begin()
+        if stroke > 1:
+            with pytest.raises(V.VrtError, match="batch is open"):
+                a.dispatch(W, H, 0)
+            a.patch_end()
+        peak = max(peak, a.scene_info()["n_records"])
+    # what the patches leave behind is reclaimed by the library itself (vrt_compact from vrt_patch_plan): the arrays never
+    # grow past about twice the live tree
+    live = V.build_layout(w2.flatten()[0])[1].n_records
+    assert batches >= 5 and peak < 3 * live + 8192 and a.scene_info()["n_records"] < 2 * live + 8192, (peak, live, refused)
+    a.compact()
+    assert a.scene_info()["n_records"] == live
     tex, dim = w2.flatten()
     b.upload_octree(tex, dim)
     info = a.scene_info()

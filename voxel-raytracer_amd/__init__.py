@@ -146,6 +146,9 @@ def hip_lib():
         L.vrt_device.argtypes = [C.c_void_p]
         L.vrt_set_variant.argtypes = [C.c_void_p, C.c_int]
         L.vrt_variant_available.argtypes = [C.c_int]
+        L.vrt_patch_begin.argtypes = [C.c_void_p]
+        L.vrt_patch_end.argtypes = [C.c_void_p]
+        L.vrt_compact.argtypes = [C.c_void_p]
         L.vrt_dispatch_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.vrt_dispatch_wait.argtypes = [C.c_void_p, C.c_int]
         L.vrt_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
@@ -561,6 +564,15 @@ class Context:
                 return plan.depth
             max_depth = plan.depth - 1
         return None
+
+    def patch_begin(self):
+        self._chk(self._L.vrt_patch_begin(self._h))
+
+    def patch_end(self):
+        self._chk(self._L.vrt_patch_end(self._h))
+
+    def compact(self):
+        self._chk(self._L.vrt_compact(self._h))
 
     def dispatch_views(self, width, height, tile_rows, shard, n_shards, mode, views, stream=None):
         """views: sequence of (inv_proj, inv_view, cam_pos, d_rgba8, d_id_dist) or a prepared (View * n) array;

@@ -607,4 +607,32 @@ bool apply_patch(std::vector<Record> &recs, WideTree &wide, bool wide_in_use, co
     return true;
 }
 
+void compact_records(std::vector<Record> &records) {
+    if (records.empty()) return;
+    std::vector<Record> out;
+    out.reserve(records.size());
+    std::vector<uint32_t> old_of;      // old index of out[i]
+    std::vector<uint8_t> is_leaf;
+    out.push_back(records[0]);
+    old_of.push_back(0u);
+    is_leaf.push_back(0);
+    for (size_t i = 0; i < out.size(); ++i) {   // breadth first: out grows while it is walked
+        if (is_leaf[i]) continue;
+        const Record r = records[old_of[i]];
+        const uint32_t mask = r.w0 & 0xffu, leaf_mask = (r.w0 >> 8) & 0xffu;
+        const uint32_t n_child = (uint32_t)__builtin_popcount(mask);
+        if (n_child == 0 || (size_t)r.w1 + n_child > records.size()) { out[i].w0 = r.w0 & ~0xffffu; out[i].w1 = 0; continue; }
+        out[i].w1 = (uint32_t)out.size();
+        uint32_t rank = 0;
+        for (uint32_t ci = 0; ci < 8; ++ci) {
+            if (!((mask >> ci) & 1u)) continue;
+            const uint32_t old = r.w1 + rank++;
+            out.push_back(records[old]);
+            old_of.push_back(old);
+            is_leaf.push_back((uint8_t)((leaf_mask >> ci) & 1u));
+        }
+    }
+    records.swap(out);
+}
+
 }  // namespace vrt

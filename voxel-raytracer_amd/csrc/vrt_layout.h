@@ -163,6 +163,11 @@ size_t stream_texels(const Record *records, size_t n_records, uint32_t top);
 bool extract_subtree(const std::vector<Record> &records, const uint8_t *path, int depth, std::vector<Record> &sub,
                      const int *toward = nullptr, const int *wmin = nullptr, const int *wmax = nullptr);
 
+// Drops what patches left behind: the records reachable from the root, re-laid in level order (children of a node
+// contiguous, after their parent -- the invariants of build_layout), everything else gone. The wide layout built over the
+// old indices is void afterwards.
+void compact_records(std::vector<Record> &records);
+
 // sub: A's new sub-tree, n_sub records, sub[0] = A as an internal record (its child mask may be empty). False (nothing
 // modified) when sub is malformed.
 bool apply_patch(std::vector<Record> &records, WideTree &wide, bool wide_in_use, const PatchSite &site, const Record *sub,
