@@ -200,7 +200,7 @@ def issue_roofline(args, kernel_ms_mean, rows_local, H):
     t_issue_ms = cycles / m["simds"] / (m["clock_ghz"] * 1e9) * 1e3
     return {"bound": "valu-issue", "valu_insts_per_launch": int(e["valu_insts_per_launch"] * share),
             "salu_insts_per_launch": int(e["salu_insts_per_launch"] * share),
-            "cycles_per_inst": round(e["simd_issue_cycles_per_launch"] / (e["valu_insts_per_launch"] + e["salu_insts_per_launch"]), 3),
+            "cycles_per_valu_inst": m["cycles_per_inst"], "pricing": "every vector instruction at the full-rate cost (a floor)",
             "clock_ghz": m["clock_ghz"], "simds": m["simds"], "issue_time_ms": round(t_issue_ms, 5),
             "frac": round(t_issue_ms / kernel_ms_mean, 4),
             "quoted_from": "profiles/r02_issue_model.json (PMC SQ_INSTS_VALU/SALU of this workload x tools/micro/valu_rate table)"}

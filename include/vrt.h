@@ -274,10 +274,11 @@ int vrt_variant_available(int variant);
 
 /* Feedback scheduling of the tracing kernel and the display pass (on by default, period 16). Frames that repeat a
  * launch shape on a stream -- the reference's loop dispatches the same W x H every frame (main.cpp:946) -- start
- * their tiles heaviest first, using the tile times measured on every `period`-th of those launches; this shortens the
- * tail of a launch (1080p dragon: primary rays -10 %, full shader -13 %, display pass -17 %); a jump of the camera
- * triggers a fresh measurement at once. Pixels do not depend on it. period = 0 switches it off: tiles then start in row-major order. Applies to one-view launches of the default
- * variant in all three modes and to vrt_denoise / vrt_dispatch_frame. */
+ * their tiles heaviest first, using the tile times measured on the shape's second launch (the first may be cold) and
+ * on every `period`-th one after it (period 1: on all of them); this shortens the tail of a launch (1080p dragon:
+ * primary rays -10 %, full shader -13 %, display pass -17 %); a jump of the camera triggers a fresh measurement at
+ * once. Pixels do not depend on it. period = 0 switches it off: tiles then start in row-major order. Applies to
+ * one-view launches of the default variant in all three modes and to vrt_denoise / vrt_dispatch_frame. */
 int vrt_set_tile_scheduling(vrt_ctx *ctx, int period);
 
 const char *vrt_version(void);

@@ -681,6 +681,9 @@ def test_feedback_tile_scheduling_never_changes_pixels(V, O, product_scenes):
                 _assert_same(rgba, ref_rgba, f"{W}x{H} mode {mode} period {period} frame {k} rgba8")
                 _assert_same(idd, ref_id, f"{W}x{H} mode {mode} period {period} frame {k} id/dist")
                 o = c.sched_order()
+                if k == 0 and period > 1:
+                    assert o.size == 0        # a shape's first launch is never the measured one (it may be cold)
+                    continue
                 assert o.size == n_wg and np.array_equal(np.sort(o), np.arange(n_wg, dtype=np.uint32)), (W, H, k)
                 seen_orders.append(o)
             assert any(not np.array_equal(o, np.arange(n_wg)) for o in seen_orders)   # it does reorder

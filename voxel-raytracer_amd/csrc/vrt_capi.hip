@@ -334,6 +334,11 @@ bool camera_jumped(const float was[6], const float now[6]) {
     return !(dot * dot >= 0.98f * n0 * n1 && dot >= 0.0f);  // cos(8 deg)^2 = 0.98
 }
 
+// Which launches of a shape record tile times: the second one (warm), then every period-th; period 1 = all of them.
+static inline bool measuring_launch(uint64_t launches, int period) {
+    return period == 1 || launches % (uint64_t)period == 1;
+}
+
 // After a measuring launch, on the same stream: reads that launch's ticks, rewrites the order the next launches read.
 int launch_order_kernel(vrt_ctx *c, SchedState *st, hipStream_t s) {
     bool &raised = c->order_lds_raised;   // per context, i.e. per device: the attribute does not carry over to another one
@@ -487,7 +492,9 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
             // eye = invView's translation column, viewing direction = minus its third column (column-major)
             const float *iv = vs.v[0].inv_view;
             const float now[6] = {iv[12], iv[13], iv[14], -iv[8], -iv[9], -iv[10]};
-            measure = st->launches % (uint64_t)c->sched_period == 0 || (st->valid && camera_jumped(st->cam, now));
+            // the first launch of a shape is never the one measured: it may be the process's first launch of the kernel
+            // (code object load, cold instruction cache and TLB), and its tile times would shape the next period's order
+            measure = measuring_launch(st->launches, c->sched_period) || (st->valid && camera_jumped(st->cam, now));
             if (measure) std::memcpy(st->cam, now, sizeof now);
             a.group_order = st->valid ? st->d_order : nullptr;
             a.tile_cost = measure ? st->d_cost : nullptr;
@@ -1297,7 +1304,7 @@ int vrt_denoise(vrt_ctx *c, int width, int height, const void *d_rgba8, const vo
         if (!st) {
             hipLaunchKernelGGL((denoise_px_kernel<2, 16>), grid, dim3(kTW / 2, 16), 0, s, a);
         } else {
-            const bool measure = st->launches % (uint64_t)c->sched_period == 0;
+            const bool measure = measuring_launch(st->launches, c->sched_period);
             a.group_order = st->valid ? st->d_order : nullptr;
             if (measure) {
                 a.tile_cost = st->d_cost;
