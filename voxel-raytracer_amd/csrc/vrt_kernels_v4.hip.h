@@ -1,15 +1,20 @@
 // vrt_kernels_v4.hip.h -- traversal variant "v4": the wide-node lookup of v3, with the march loop rebuilt around what
 // a gfx950 SIMD charges per instruction.
 //
-// Measured (tools/micro/valu_rate, profiles/r02_valu_rate.txt; SIMD ticks per wave-instruction with 6-8 waves resident):
-//   v_add/sub/mul_f32 0.6-0.9 | v_floor/fract 1.0-1.3 | v_fma_f32 1.2-1.4 | v_and/xor/add/sub_u32, v_lshrrev (vgpr) 1.4-1.65
-//   | v_min/max_f32, v_min3 1.5-2.0 | v_mov 1.6-1.8 | v_cmp 2.0-2.7 | EVERY scalar instruction 2.0-2.7 | v_cndmask 2.7-2.9
-//   | VOP3 integer (bfe, lshl_or, or3, add3, add_lshl, mad_u24), shifts by a constant, v_pk_*_f32, v_cvt_* 2.6-3.0
-//   | a taken branch 3-3.5 (18 ticks of the wave's own time).
-// The v3 kernel spends 2,287 instructions per wave at a mean of 2.2 ticks: 30 % of them scalar mask bookkeeping for
-// divergent exits and nested loops, 14 v_mov per step for loop-carried values, packed f32 arithmetic that costs more
-// than the two plain instructions it replaces, integer shifts to rebuild the node planes. Its SIMD issue time equals
-// the launch time: the kernel is issue bound, so the remedy is a cheaper instruction stream, not more waves.
+// Measured (tools/micro/valu_rate, profiles/r02_valu_rate.txt; SIMD ticks per wave64 instruction by the launch's wall
+// time with 6-8 waves resident -- the third column; the per-wave s_memtime columns under-read because the probe's own
+// registers limit how many of its waves are resident):
+//   2.5-2.6  v_add/sub/mul/fma_f32, v_and/xor/add/sub_u32, v_lshrrev by a VGPR amount, v_mov
+//   4.3-4.6  v_cmp, v_cndmask, v_floor/fract, v_min/max/med3, v_cvt_*, shifts by a constant, every VOP3 integer op (bfe,
+//            lshl_or, or3, add3, lshl_add, mad_u24, perm, bfi), v_pk_*_f32, v_readfirstlane; every scalar instruction and
+//            a branch not taken cost the same on the scalar port, which overlaps with the vector one (v_add + s_add: 2.65
+//            per pair)
+//   8.4      v_rcp / v_sqrt / v_rsq
+// The v3 kernel spends 2,287 instructions per wave: 30 % of them scalar mask bookkeeping for divergent exits and nested
+// loops, 14 v_mov per step for loop-carried values, packed f32 arithmetic that costs as much as the two plain
+// instructions it replaces and more than one, integer shifts and conversions to rebuild the node planes. Its vector
+// issue time is within 20 % of the launch time: the kernel is issue bound, so the remedy is a cheaper instruction
+// stream, not more waves.
 //
 // What v4 changes (outputs identical: the lookup still returns octreeFind's node, the DDA arithmetic is untouched):
 //   * the exit axis, the hit flag and the ray status live in vector registers, so leaving the loop needs one mask
@@ -18,7 +23,7 @@
 //     anchor is inside the world by construction;
 //   * "no current node" is a walk state whose tests cannot pass (cell shift 0 and a `last` point no representable
 //     floor() can come within 4 of), not an extra flag;
-//   * planes, min-axis selection and the push in plain f32 / integer ops chosen from the table above: the cells are read
+//   * planes, min-axis selection and the push in plain f32 / integer ops from the first row of the table above: the cells are read
 //     in a second form (vrt_layout.h to_cell4) that carries 2^t as a float exponent, so a node's planes are
 //     (floor(floor(p) * 2^-t) + dpos) * 2^t in four f32 operations per axis -- every step exact, hence the same floats
 //     the integer arithmetic gives -- the child node as a byte offset, and the medium byte with 85 for empty space, so
