@@ -57,6 +57,8 @@ def parse_args(argv=None):
     ap.add_argument("--tile-rows", type=int, default=8)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ray-tables", action="store_true",
+                    help="A/B: every launch runs the shader's own ray-generation prologue (vrt_debug_set_ray_tables(0))")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket launches with hipEvents (roofline is then omitted); for measuring their cost")
     ap.add_argument("--gather", default="auto", choices=["auto", "final", "frame"],
@@ -273,6 +275,8 @@ def main():
 
     ctx = V.Context(dev_index)
     ctx.set_variant(args.variant)
+    if args.no_ray_tables:
+        ctx.set_ray_tables(False)
     ctx.set_tile_scheduling(args.sched_period)
     ctx.upload_octree(tex, dim)
     ctx.set_camera(ip, iv, cp)
@@ -520,7 +524,7 @@ def main():
                            "mappings of rank 0's frame buffers (xGMI peer stores, stream flags, four slots)"
                            if delivery_used == "peer_store_rank0" else delivery),
                        "gather": gather, "delivery": delivery_used, "streams": n_streams, "tile_scheduling_period": args.sched_period,
-                       "variant": args.variant, "collective_backend": args.backend if world > 1 else None,
+                       "variant": args.variant, "ray_tables": not args.no_ray_tables, "collective_backend": args.backend if world > 1 else None,
                        "launcher": launcher},
             "roofline": roofline,
             "issue_roofline": issue,

@@ -889,6 +889,87 @@ def test_seeded_random_scenes_uniforms_and_cameras(ctx, V, O):
     assert frames_with_hits >= 15 and hit_pixels > 5000, (frames_with_hits, hit_pixels)   # the sweep looked at geometry
 
 
+def test_ray_generation_tables_in_range_math_and_host_light_setup(ctx, V, O, product_scenes):
+    """The prologue in its two forms (View::gen_fast: per-column / per-row tables from the dispatcher + in-range 1/x and
+    sqrt; otherwise the shader's operations one by one) and the shadow ray's set-up made by the dispatcher:
+      * rcp_inrange / sqrt_inrange against correctly rounded values over their whole stated ranges;
+      * standard projections: tables on == tables off == oracle, all modes, ragged frame sizes (odd and even: an even size
+        has a column / row with u = 0 or v = 0, where the sign of a zero term decides);
+      * projections the table builder must refuse (sheared, off-centre with a u-dependent w, y flipped: the v = 0 row's
+        zero would change sign with the column) and an inverse view matrix out of range (scaled 1e-25): still the oracle's
+        frames, through the shader's own prologue;
+      * light directions with zero, negative and unnormalised components, primary + shadow."""
+    rng = np.random.default_rng(77)
+    # in-range math, bit for bit: numpy's float32 division and sqrt are correctly rounded
+    e = rng.uniform(-94.9, 125.9, size=400000)
+    x = (np.exp2(e) * rng.choice([-1.0, 1.0], size=e.size)).astype(np.float32)
+    x = np.concatenate([x, np.float32([2.0 ** -95, -2.0 ** -95, 2.0 ** 125, 1.0, -1.0, 3.0, 1e-8, 0.99999994, 1.0000001,
+                                       np.nextafter(np.float32(2.0 ** 126), np.float32(0))])]).astype(np.float32)
+    def same_bits(got, want, arg, what):
+        bad = np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))
+        assert bad.size == 0, f"{what}: {bad.size} of {arg.size} differ; first: f({arg[bad[0]]!r}) = {got[bad[0]]!r}, want {want[bad[0]]!r}; " \
+                              f"arguments {[float(v) for v in arg[bad[:8]]]}"
+    got = ctx.debug_math(30, x, x)
+    same_bits(got, np.float32(1.0) / x, x, "rcp_inrange vs 1/x")
+    e = rng.uniform(-95.9, 127.9, size=400000)
+    y = np.exp2(e).astype(np.float32)
+    y = np.concatenate([y, np.float32([2.0 ** -96, 1.0, 2.0, 3.0, 4.0, 0.99999994, 1.0000001, 3.4028235e38, 2.0 ** -95, 2.0 ** -94])]).astype(np.float32)
+    got = ctx.debug_math(31, y, y)
+    same_bits(got, np.sqrt(y), y, "sqrt_inrange vs sqrt")
+
+    tex, dim = product_scenes["dragon"]
+    ctx.upload_octree(tex, dim)
+    ctx.set_params(ctx.default_params())
+    pose = (63.5, 60.5, 140.5, -90.0, -10.0)
+    try:
+        for (W, H) in [(96, 54), (97, 55), (64, 64), (33, 20)]:
+            ip, iv, cp, _ = V.camera_block(pose[:3], pose[3], pose[4], W, H)
+            assert V.ray_table(ip, W, H) is not None and V.view_in_range(iv)
+            ctx.set_camera(ip, iv, cp)
+            for mode in (0, 1, 2):
+                ref_rgba, ref_id, _ = _oracle_frame(O, tex, dim, (ip, iv, cp), W, H, mode)
+                for tables in (True, False):
+                    ctx.set_ray_tables(tables)
+                    rgba, idd = ctx.dispatch(W, H, mode)
+                    _assert_same(rgba, ref_rgba, f"{W}x{H} mode {mode} tables {tables} rgba8")
+                    _assert_same(idd, ref_id, f"{W}x{H} mode {mode} tables {tables} id/dist")
+        ctx.set_ray_tables(True)
+        W, H = 96, 54
+        ip, iv, cp, _ = V.camera_block(pose[:3], pose[3], pose[4], W, H)
+        exotic = []
+        m = np.array(ip, np.float32).copy(); m[4] = 0.05; exotic.append(("sheared", m, iv))                 # x depends on v
+        m = np.array(ip, np.float32).copy(); m[3] = 0.01; exotic.append(("w depends on u", m, iv))
+        m = np.array(ip, np.float32).copy(); m[5] = -m[5]; exotic.append(("y flipped", m, iv))             # zero of the v = 0 row changes sign
+        small = np.array(iv, np.float32).copy(); small[:12] *= np.float32(1e-25); exotic.append(("tiny view matrix", np.array(ip, np.float32), small))
+        for name, m, view in exotic:
+            if name == "tiny view matrix":
+                assert not V.view_in_range(view)
+            else:
+                assert V.ray_table(m, W, H) is None, name
+            ctx.set_camera(m, view, cp)
+            for mode in (0, 1):
+                ref_rgba, ref_id, _ = _oracle_frame(O, tex, dim, (m, view, cp), W, H, mode)
+                rgba, idd = ctx.dispatch(W, H, mode)
+                _assert_same(rgba, ref_rgba, f"{name} mode {mode} rgba8")
+                _assert_same(idd, ref_id, f"{name} mode {mode} id/dist")
+            assert np.count_nonzero(ref_id[..., 0]) > 200 or name == "tiny view matrix", name
+        # the shadow ray's set-up on the host
+        ctx.set_camera(ip, iv, cp)
+        for ld in [(0.0, 1.0, 0.0), (0.0, 0.5, -2.0), (-3.0, 4.0, 0.0), (1e-9, 0.7, 0.7), (-0.3, -0.9, 0.2), (0.5, 0.5, 0.5)]:
+            p = ctx.default_params()
+            p.light_dir[:] = [float(np.float32(v)) for v in ld]
+            ctx.set_params(p)
+            s = O.make_scene(tex, dim, ip, iv, cp)
+            s.light_dir[:] = [float(np.float32(v)) for v in ld]
+            ref_rgba, ref_id, _, _ = O.render(s, W, H, 1)
+            rgba, idd = ctx.dispatch(W, H, 1)
+            _assert_same(rgba, ref_rgba, f"light {ld} rgba8")
+            _assert_same(idd, ref_id, f"light {ld} id/dist")
+    finally:
+        ctx.set_ray_tables(True)
+        ctx.set_params(ctx.default_params())
+
+
 def test_fused_frame_call_equals_dispatch_then_display_pass(ctx, V, product_scenes):
     """vrt_dispatch_frame keeps the two intermediate images on the device; all three results must equal the
     two-call route, at a size off every tile edge."""

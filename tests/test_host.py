@@ -482,3 +482,48 @@ def test_malformed_texel_streams_are_refused_or_laid_out_never_crash(V, product_
             out, (n_nodes, n_roots) = res
             assert n_roots <= 8
     assert laid_out > 100 and refused > 10, (laid_out, refused)
+
+
+def test_ray_table_is_the_shader_formula_per_column_and_row(V):
+    """vrt_debug_ray_table (what the dispatcher uploads for the kernels' table-driven prologue) against the shader's
+    operations in numpy float32 (IEEE, like the host code): u = px / W * 2 - 1, invProjection * (u, v, -1, 1) with the
+    association of mat_vec(), division by w (comp:626-634). Refusals: projections whose x depends on v, whose w varies,
+    whose zero terms change sign over the frame, non-finite entries."""
+    f = np.float32
+    for (W, H, pose) in [(1920, 1080, (63.5, 60.5, 140.5, -90.0, -10.0)), (1280, 720, (48.5, 60.5, 170.5, -90.0, -12.0)),
+                         (97, 55, (1.5, 2.5, 3.5, 30.0, 40.0)), (1, 1, (0.5, 0.5, 0.5, 0.0, 0.0))]:
+        ip, iv, cp, _ = V.camera_block(pose[:3], pose[3], pose[4], W, H)
+        m = np.array(ip, f)
+        t = V.ray_table(ip, W, H)
+        assert t is not None, (W, H)
+        x, y, z = t
+
+        def row(r, u, v):
+            return (m[0 + r] * u + m[4 + r] * v) + (m[8 + r] * f(-1.0) + m[12 + r] * f(1.0))
+        u = (np.arange(W, dtype=f) / f(W)) * f(2.0) - f(1.0)
+        v = (np.arange(H, dtype=f) / f(H)) * f(2.0) - f(1.0)
+        w = row(3, f(1.0), f(1.0))
+        assert abs(w) > 1e-6
+        assert np.array_equal((row(0, u, f(1.0)) / w).view(np.uint32), x.view(np.uint32))
+        assert np.array_equal((row(0, u, f(-1.0)) / w).view(np.uint32), x.view(np.uint32))   # no trace of v, not even a zero's sign
+        assert np.array_equal((row(1, f(1.0), v) / w).view(np.uint32), y.view(np.uint32))
+        assert np.array_equal((row(1, f(-1.0), v) / w).view(np.uint32), y.view(np.uint32))
+        assert f(row(2, f(1.0), f(1.0)) / w).view(np.uint32) == f(z).view(np.uint32)
+        assert V.view_in_range(iv)
+    ip, iv, cp, _ = V.camera_block((63.5, 60.5, 140.5), -90.0, -10.0, 96, 54)
+    for k, val in [(4, 0.05), (1, -0.2), (8, 1e-3), (3, 0.01), (7, 0.5), (2, 1.0), (0, float("nan")), (15, float("inf"))]:
+        m = np.array(ip, f).copy()
+        m[k] = val
+        assert V.ray_table(m, 96, 54) is None, k
+    m = np.array(ip, f).copy()
+    m[5] = -m[5]                     # the row with v = 0: (+-0 from 0 * u) + (-0) keeps the sign of the column's zero
+    assert V.ray_table(m, 96, 54) is None
+    assert V.ray_table(m, 96, 55) is not None    # an odd height has no such row
+    m = np.array(ip, f).copy()
+    m[11] = 0.0; m[15] = 0.0         # w == 0: the shader skips the division (|w| <= 1e-6)
+    t = V.ray_table(m, 8, 8)
+    assert t is not None and t[2] == f(-1.0) * m[10] + m[14] * f(1.0) or t is None
+    bad = np.array(iv, f).copy(); bad[:12] *= f(1e-25)
+    assert not V.view_in_range(bad)
+    bad = np.array(iv, f).copy(); bad[0:3] = bad[4:7]      # singular
+    assert not V.view_in_range(bad)

@@ -180,6 +180,7 @@ def hip_lib():
         L.vrt_multi_stream.restype = C.c_void_p
         L.vrt_multi_stream.argtypes = [C.c_void_p]
         L.vrt_debug_set_full_split.argtypes = [C.c_void_p, C.c_int]
+        L.vrt_debug_set_ray_tables.argtypes = [C.c_void_p, C.c_int]
         L.vrt_debug_set_bounce.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.vrt_version.restype = C.c_char_p
         L.vrt_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -363,6 +364,26 @@ def patch_check(texels_before, texels_after, voxel, points, world_min=(-1023, -1
     if r < 0:
         raise VrtError(f"vrt_debug_patch_check failed ({r})")
     return int(r), int(info[0]), int(info[1]), int(info[2]), bool(info[3])
+
+
+def ray_table(inv_projection, width, height):
+    """Host-only: the per-column / per-row ray-generation table of a projection (vrt_debug_ray_table)
+    -> (x[width], y[height], z) float32, or None when the projection has no table."""
+    L = hip_lib()
+    L.vrt_debug_ray_table.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    m = np.ascontiguousarray(inv_projection, np.float32).reshape(16)
+    x, y, z = np.zeros(width, np.float32), np.zeros(height, np.float32), np.zeros(1, np.float32)
+    r = L.vrt_debug_ray_table(m.ctypes.data, width, height, x.ctypes.data, y.ctypes.data, z.ctypes.data)
+    if r < 0:
+        raise VrtError(f"vrt_debug_ray_table failed ({r})")
+    return (x, y, float(z[0])) if r == 1 else None
+
+
+def view_in_range(inv_view):
+    L = hip_lib()
+    L.vrt_debug_view_in_range.argtypes = [C.c_void_p]
+    m = np.ascontiguousarray(inv_view, np.float32).reshape(16)
+    return L.vrt_debug_view_in_range(m.ctypes.data) == 1
 
 
 def wide_find(texels, points, world_min=(-1023, -1023, -1023), world_max=(1024, 1024, 1024)):
@@ -627,6 +648,10 @@ class Context:
     @property
     def stream(self):
         return self._L.vrt_stream(self._h)
+
+    def set_ray_tables(self, on):
+        """A/B: False = every launch runs the shader's own ray-generation prologue (no per-projection tables)"""
+        self._chk(hip_lib().vrt_debug_set_ray_tables(self._h, 1 if on else 0))
 
     def debug_math(self, op, x, y):
         x = np.ascontiguousarray(x, np.float32)

@@ -170,6 +170,19 @@ struct vrt_ctx {
     std::vector<SchedState> sched;
     uint64_t sched_tick = 0;
     bool order_lds_raised = false;            // tile_order_kernel's dynamic-LDS ceiling raised on THIS context's device
+    // ray-generation tables, one per (inverse projection, width, height) seen lately (ray_table() below)
+    struct RayTable {
+        float inv_proj[16]{};
+        int width = 0, height = 0;
+        bool ok = false;            // the projection has the separable shape and the tables are on the device
+        float z = 0.0f;
+        float *d_tab = nullptr;     // width floats (x per column) then height floats (y per row)
+        size_t capacity = 0;        // floats
+        uint64_t last_use = 0;
+    };
+    std::vector<RayTable> ray_tables;
+    uint64_t ray_tick = 0;
+    bool ray_tables_on = true;                   // vrt_debug_set_ray_tables(0): always the shader's own prologue (A/B, tests)
     const uint32_t *dbg_group_order = nullptr;  // vrt_debug_set_tile_order: caller-owned buffers instead of the scheduler's
     uint32_t *dbg_tile_cost = nullptr;
     bool dbg_sched = false;
@@ -354,6 +367,109 @@ int launch_order_kernel(vrt_ctx *c, SchedState *st, hipStream_t s) {
     return VRT_OK;
 }
 
+// ---- ray generation, the part that does not depend on the pixel as a whole ---------------------------------------------
+// comp:626-634: u = px / W * 2 - 1, v likewise, view = invProjection * (u, v, -1, 1), view /= view.w. For the inverse of
+// any perspective or orthographic projection x depends on u alone, y on v alone, z and w on neither, so the W + H + 1
+// distinct values are computed here once per (matrix, W, H) -- by the SAME float operations in the same order, which is
+// what makes them the same bits (this file is compiled with -ffp-contract=off like the kernels; x86-64 float arithmetic is
+// IEEE binary32) -- and the kernels read them (View::gen_x/gen_y/gen_z) instead of making two integer->float conversions,
+// five divisions and a 4x4 product per pixel. A zero term's SIGN can depend on the other coordinate ((+0) * v): each value
+// is therefore evaluated with the other coordinate at +1 and at -1 and must come out the same bits, otherwise the table
+// is refused and the kernels run the shader's own prologue. Returns false when the matrix is not of that shape.
+bool build_ray_table(const float *m, int W, int H, std::vector<float> &tab, float &z_out) {
+    static const int kZeros[10] = {4, 8, 12, 1, 9, 13, 2, 6, 3, 7};   // column-major m[c * 4 + r]
+    for (int k : kZeros)
+        if (!(m[k] == 0.0f)) return false;
+    const auto row = [&](int r, float u, float v) {   // mat_vec() of vrt_common.hip.h with (x, y, z, w) = (u, v, -1, 1)
+        return (m[0 * 4 + r] * u + m[1 * 4 + r] * v) + (m[2 * 4 + r] * -1.0f + m[3 * 4 + r] * 1.0f);
+    };
+    const auto same = [](float a, float b) { return std::memcmp(&a, &b, sizeof a) == 0; };
+    const float w = row(3, 1.0f, 1.0f), z = row(2, 1.0f, 1.0f);
+    for (int k = 1; k < 4; ++k) {
+        const float u = (k & 1) ? -1.0f : 1.0f, v = (k & 2) ? -1.0f : 1.0f;
+        if (!same(row(3, u, v), w) || !same(row(2, u, v), z)) return false;
+    }
+    if (!(w == w) || !(z == z)) return false;
+    const bool divide = fabsf(w) > 1e-6f;
+    tab.resize((size_t)W + (size_t)H);
+    double hi = 0.0;
+    for (int px = 0; px < W; ++px) {
+        const float u = ((float)px / (float)W) * 2.0f - 1.0f;
+        const float x = row(0, u, 1.0f);
+        if (!same(x, row(0, u, -1.0f))) return false;
+        const float q = divide ? x / w : x;
+        if (!(fabs((double)q) <= 1.0995e12)) return false;   // 2^40; also refuses NaN
+        hi = fabs((double)q) > hi ? fabs((double)q) : hi;
+        tab[(size_t)px] = q;
+    }
+    for (int py = 0; py < H; ++py) {
+        const float v = ((float)py / (float)H) * 2.0f - 1.0f;
+        const float y = row(1, 1.0f, v);
+        if (!same(y, row(1, -1.0f, v))) return false;
+        const float q = divide ? y / w : y;
+        if (!(fabs((double)q) <= 1.0995e12)) return false;
+        tab[(size_t)W + (size_t)py] = q;
+    }
+    z_out = divide ? z / w : z;
+    // range of the first normalisation, dot = (x^2 + y^2) + z^2 >= z^2: inside [2^-80, 2^82], its root inside [2^-40, 2^41]
+    const double az = fabs((double)z_out);
+    return az >= 9.0949e-13 && az <= 1.0995e12;   // 2^-40 .. 2^40
+}
+
+// The second normalisation takes |invView3x3 * d| for a unit d: between the matrix' smallest and largest singular value.
+// With F2 the squared Frobenius norm, sigma_max <= sqrt(F2) and sigma_min = |det| / (sigma_1 sigma_2) >= 2 |det| / F2.
+// True when that keeps the squared length inside [2^-62, 2^42] with room for the rounding of the product.
+bool view_matrix_in_range(const float *m) {
+    double a[3][3], f2 = 0.0;
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) { a[r][c] = (double)m[c * 4 + r]; f2 += a[r][c] * a[r][c]; }
+    if (!(f2 >= 9.0949e-13 && f2 <= 1.0995e12)) return false;      // 2^-40 .. 2^40, refuses NaN
+    const double det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                       a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+    return det * det >= 2.3842e-7 * f2 * f2 * f2;                   // sigma_min >= 2^-10 sqrt(F2)  <=  det^2 >= 2^-22 F2^3
+}
+
+// The view's table, from the cache or built and uploaded now (a synchronous 12 KB copy, once per projection and frame
+// shape). nullptr: this projection has no table. Eight tables are kept; the least recently used one is replaced after a
+// device synchronize (launches on any stream may still read it).
+vrt_ctx::RayTable *ray_table(vrt_ctx *c, const float *inv_proj, int W, int H) {
+    if (!c->ray_tables_on) return nullptr;
+    vrt_ctx::RayTable *hit = nullptr, *lru = nullptr;
+    for (auto &t : c->ray_tables) {
+        if (t.width == W && t.height == H && std::memcmp(t.inv_proj, inv_proj, sizeof t.inv_proj) == 0) hit = &t;
+        if (!lru || t.last_use < lru->last_use) lru = &t;
+    }
+    if (hit) {
+        hit->last_use = ++c->ray_tick;
+        return hit->ok ? hit : nullptr;
+    }
+    std::vector<float> tab;
+    float z = 0.0f;
+    const bool ok = build_ray_table(inv_proj, W, H, tab, z);
+    vrt_ctx::RayTable *t;
+    if (c->ray_tables.size() < 8) {
+        c->ray_tables.emplace_back();
+        t = &c->ray_tables.back();
+    } else {
+        t = lru;
+        if (t->ok && hipDeviceSynchronize() != hipSuccess) return nullptr;
+    }
+    std::memcpy(t->inv_proj, inv_proj, sizeof t->inv_proj);
+    t->width = W; t->height = H; t->z = z; t->ok = false;
+    t->last_use = ++c->ray_tick;
+    if (!ok) return nullptr;
+    if (tab.size() > t->capacity) {
+        float *fresh = nullptr;
+        if (hipMalloc((void **)&fresh, tab.size() * sizeof(float)) != hipSuccess) return nullptr;
+        if (t->d_tab) (void)hipFree(t->d_tab);
+        t->d_tab = fresh;
+        t->capacity = tab.size();
+    }
+    if (hipMemcpy(t->d_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    t->ok = true;
+    return t;
+}
+
 // Builds the kernel arguments for local rows [0, n_rows) and enqueues one launch.
 int ensure_analysis(vrt_ctx *c);
 
@@ -417,6 +533,12 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
             w.first_w0 = ff.w0; w.first_w1 = ff.w1; w.first_node = ff.node; w.first_anode = ff.anode;
             w.first_s = ff.s; w.first_as = ff.as;
         }
+        w.gen_x = w.gen_y = nullptr; w.gen_z = 0.0f; w.gen_fast = 0u;
+        if (view_matrix_in_range(w.inv_view)) {
+            if (const vrt_ctx::RayTable *t = ray_table(c, w.inv_proj, width, height)) {
+                w.gen_x = t->d_tab; w.gen_y = t->d_tab + width; w.gen_z = t->z; w.gen_fast = 1u;
+            }
+        }
     }
     if (v.trav == 4 && mode != VRT_MODE_FULL) {
         // the v4 primary kernels hold the march loop for rays that start in refraction byte 85 (1.0) only: an eye inside a
@@ -434,6 +556,12 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
         a.wmax[i] = c->params.world_max[i];
         a.light_dir[i] = c->params.light_dir[i];
         a.highlighted[i] = c->params.highlighted[i];
+        // comp:335-345 on the launch's one light direction
+        const float d = a.light_dir[i];
+        a.light_inv[i] = (fabsf(d) < 1e-8f) ? 1e20f : 1.0f / d;
+        a.light_push[i] = (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * 0.001f;
+        a.light_dpos[i] = d > 0.0f ? 1 : 0;
+        a.light_dposf[i] = d > 0.0f ? 1.0f : 0.0f;
     }
     for (int i = 0; i < 4; ++i) a.global_light[i] = c->params.global_light[i];
     a.tex_dim = (int)c->info.tex_dim;
@@ -693,6 +821,8 @@ void vrt_destroy(vrt_ctx *c) {
         if (ln.done) (void)hipEventDestroy(ln.done);
     }
     for (auto &e : c->prof_events) (void)hipEventDestroy(e);
+    if (!c->ray_tables.empty()) (void)hipDeviceSynchronize();
+    for (auto &t : c->ray_tables) (void)hipFree(t.d_tab);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1411,6 +1541,29 @@ int vrt_debug_set_full_split(vrt_ctx *c, int on) {
     return VRT_OK;
 }
 
+// Host-only (tests): the ray-generation table the dispatcher would build for this inverse projection and frame shape.
+// Returns 1 and fills out_x[width], out_y[height], out_z when the projection has a table, 0 when it has none.
+int vrt_debug_ray_table(const float inv_projection[16], int width, int height, float *out_x, float *out_y, float *out_z) {
+    if (!inv_projection || width < 1 || height < 1 || !out_x || !out_y || !out_z) return VRT_E_INVALID;
+    std::vector<float> tab;
+    float z = 0.0f;
+    if (!build_ray_table(inv_projection, width, height, tab, z)) return 0;
+    std::memcpy(out_x, tab.data(), (size_t)width * sizeof(float));
+    std::memcpy(out_y, tab.data() + width, (size_t)height * sizeof(float));
+    *out_z = z;
+    return 1;
+}
+// ... and whether an inverse view matrix keeps the second normalisation in range (view_matrix_in_range())
+int vrt_debug_view_in_range(const float inv_view[16]) { return inv_view ? (view_matrix_in_range(inv_view) ? 1 : 0) : VRT_E_INVALID; }
+
+// A/B switch (tests, tools): 0 makes every launch run the shader's own ray-generation prologue, 1 (default) lets views
+// whose projection allows it read the per-column / per-row tables (ray_table())
+int vrt_debug_set_ray_tables(vrt_ctx *c, int on) {
+    if (!c) return VRT_E_INVALID;
+    c->ray_tables_on = on != 0;
+    return VRT_OK;
+}
+
 int vrt_debug_set_bounce(vrt_ctx *c, int refill_below, int waves_per_simd) {
     if (!c || refill_below < 1 || refill_below > 65 || waves_per_simd < 1 || waves_per_simd > 8) return VRT_E_INVALID;
     c->bounce_refill_below = refill_below;
@@ -1461,7 +1614,7 @@ int vrt_debug_math(vrt_ctx *c, int op, const float *x, const float *y, float *ou
     VRT_HIP(c, hipMalloc((void **)&dout, bytes));
     VRT_HIP(c, hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, c->stream));
     VRT_HIP(c, hipMemcpyAsync(dy, y, bytes, hipMemcpyHostToDevice, c->stream));
-    if (op >= 10)
+    if (op >= 10 && op < 30)
         hipLaunchKernelGGL(vrt::full::math_probe_full_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, op, dx, dy, dout, n);
     else
         hipLaunchKernelGGL(vrt::math_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, op, dx, dy, dout, n);

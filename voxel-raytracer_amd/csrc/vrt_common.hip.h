@@ -36,6 +36,14 @@ struct View {
     // the primary rays' first lookup (at the eye), made by the host for the wide kernels (vrt_layout.h first_find)
     uint32_t first_w0, first_w1, first_node, first_anode;
     int first_s, first_as, first_valid;
+    // Ray generation with its per-column and per-row parts made once per projection by the dispatcher (ray_table() in
+    // vrt_capi.hip): when the inverse projection has the shape every perspective or orthographic matrix gives it -- x
+    // depends on the column only, y on the row only, z and w on neither -- gen_x[px], gen_y[py], gen_z hold view.xyz / w
+    // of comp:630-634 (same float operations, made on the host), and gen_fast says that they do and that every
+    // normalisation of the prologue stays inside the range where 1/x and sqrt need no range scaling (primary_ray_dir()).
+    const float *gen_x, *gen_y;
+    float gen_z;
+    uint32_t gen_fast;
 };
 
 // Kernel arguments: passed by value (kernarg segment -> scalar loads, wave-uniform).
@@ -53,6 +61,10 @@ struct KArgs {
     int wmax[3];
     float global_light[4];
     float light_dir[3];
+    // the shadow ray's set-up (comp:335-345), the same for every ray of a launch: made by the dispatcher from light_dir
+    // with the shader's operations -- 1/d or 1e20, sign * 1e-3, d > 0 -- instead of 70 vector instructions per wave
+    float light_inv[3], light_push[3], light_dposf[3];
+    int light_dpos[3];
     int highlighted[3];
     int tex_dim;
     int width, height;
@@ -104,6 +116,27 @@ VRT_DEV F3 scale3(F3 a, float s) { return F3{a.x * s, a.y * s, a.z * s}; }
 VRT_DEV F3 add3(F3 a, F3 b) { return F3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 VRT_DEV F3 sub3(F3 a, F3 b) { return F3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 VRT_DEV F3 normalize3(F3 a) { return scale3(a, 1.0f / __builtin_sqrtf(dot3(a, a))); }
+
+// 1/x and sqrt(x) for arguments known to be in range: the instruction sequences the compiler emits for the correctly
+// rounded `1.0f / x` and sqrtf(x), WITHOUT their range handling -- the two v_div_scale, v_div_fmas' scale and v_div_fixup;
+// the 2^32 pre-scale, its undo and the zero/infinity class test -- 7 and 9 instructions instead of 12 and 17, and the
+// ones that go are the dear kinds (profiles/r02_valu_rate.txt). Inside the stated ranges those steps are identities, so
+// the results are the same bits (checked against correctly rounded values: vrt_debug_math ops 30 and 31).
+//   rcp_inrange : 2^-95 <= |x| < 2^126   (v_div_scale_f32 leaves 1.0 and x alone there)
+//   sqrt_inrange: 2^-96 <= x < infinity
+VRT_DEV float rcp_inrange(float x) {
+    float y = __builtin_amdgcn_rcpf(x);
+    y = __builtin_fmaf(__builtin_fmaf(-x, y, 1.0f), y, y);
+    const float q = __builtin_fmaf(__builtin_fmaf(-x, y, 1.0f), y, y);
+    return __builtin_fmaf(__builtin_fmaf(-x, q, 1.0f), y, q);
+}
+VRT_DEV float sqrt_inrange(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float below = __uint_as_float(__float_as_uint(s) - 1u), above = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r = (0.0f >= __builtin_fmaf(-below, s, x)) ? below : s;
+    return (0.0f < __builtin_fmaf(-above, s, x)) ? above : r;
+}
+VRT_DEV F3 normalize3_inrange(F3 a) { return scale3(a, rcp_inrange(sqrt_inrange(dot3(a, a)))); }
 VRT_DEV float sign_c(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
 VRT_DEV float comp(F3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
 VRT_DEV I3 floor_i3(F3 p) { return I3{(int)__builtin_floorf(p.x), (int)__builtin_floorf(p.y), (int)__builtin_floorf(p.z)}; }
@@ -130,6 +163,9 @@ struct Hit {
     int r_s, r_as;
     I3 r_last;
 };
+
+// The shadow ray's direction-dependent constants (comp:335-345), uniform over a launch: see KArgs::light_inv.
+struct LightSetup { F3 dir, inv, push, dposf; I3 dpos; };
 
 // exp() convention shared with the oracle (Cephes-style, plain mul/add)
 VRT_DEV float det_expf(float x) {
@@ -220,11 +256,19 @@ struct LateOut {
 };
 VRT_DEV LateOut late_out(LateArgs la, LateView lv) { return LateOut{lv->out_rgba, lv->out_id, la->width, la->compact, false}; }
 
-// One pixel: ray generation (comp:624-641), primary-ray pathTrace, packing of the two outputs.
-// TRAV supplies the traversal: march(), shadow(). MODE: 0 primary, 1 primary + shadow ray.
-template <int MODE, class TRAV>
-VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, int px, int py, uint32_t &rgba, int2 &idd, LateOut &lo) {
-    const float kPI = 3.14159265359f;
+// Ray generation (comp:624-641) and pathTrace's own normalisation of the direction (comp:441). Two forms, chosen per view
+// by the dispatcher (wave-uniform): the shader's operations one by one, or -- View::gen_fast -- the same operations with
+// everything that depends on the column or the row alone read from the view's tables (the two index divisions, the
+// first matrix product and the perspective divide: 8 of the prologue's 15 divisions) and the remaining 1/x and sqrt in
+// their in-range forms. Same bits either way (tests: frames of both forms against the oracle).
+VRT_DEV F3 primary_ray_dir(const KArgs &a, const View &vw, int px, int py) {
+    if (vw.gen_fast) {
+        const F3 vd = normalize3_inrange(F3{vw.gen_x[px], vw.gen_y[py], vw.gen_z});
+        float wd4[4];
+        mat_vec(vw.inv_view, vd.x, vd.y, vd.z, 0.0f, wd4);
+        const F3 d = normalize3_inrange(F3{wd4[0], wd4[1], wd4[2]});
+        return scale3(d, rcp_inrange(sqrt_inrange(dot3(d, d))));
+    }
     float u = ((float)px / (float)a.width) * 2.0f - 1.0f;
     float v = ((float)py / (float)a.height) * 2.0f - 1.0f;
     float view[4];
@@ -233,7 +277,20 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
     F3 vd = normalize3(F3{view[0], view[1], view[2]});
     float wd4[4];
     mat_vec(vw.inv_view, vd.x, vd.y, vd.z, 0.0f, wd4);
-    F3 ray_dir = normalize3(F3{wd4[0], wd4[1], wd4[2]});
+    const F3 d = normalize3(F3{wd4[0], wd4[1], wd4[2]});
+    return scale3(d, 1.0f / __builtin_sqrtf(dot3(d, d)));
+}
+
+// traversals whose shadow() takes the dispatcher's LightSetup declare `static constexpr bool kHostLight = true`
+template <class T, class = void> struct host_light { static constexpr bool value = false; };
+template <class T> struct host_light<T, decltype((void)T::kHostLight)> { static constexpr bool value = T::kHostLight; };
+
+// One pixel: ray generation (comp:624-641), primary-ray pathTrace, packing of the two outputs.
+// TRAV supplies the traversal: march(), shadow(). MODE: 0 primary, 1 primary + shadow ray.
+template <int MODE, class TRAV>
+VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, int px, int py, uint32_t &rgba, int2 &idd, LateOut &lo) {
+    const float kPI = 3.14159265359f;
+    const F3 ray_dir = primary_ray_dir(a, vw, px, py);
     F3 ray_origin{vw.cam_pos[0], vw.cam_pos[1], vw.cam_pos[2]};
 
     int voxel_id = 0;
@@ -243,8 +300,6 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
     // medium at the eye (comp:445-449): the same node for every ray of the view, found once by the dispatcher
     Decoded tvd = decode_leaf(vw.eye0, vw.eye1);
     float start_iof = (tvd.p[0] > 0.0f && tvd.p[0] < 3.0f) ? tvd.p[0] : 1.0f;
-    float inv_len = 1.0f / __builtin_sqrtf(dot3(ray_dir, ray_dir));
-    ray_dir = scale3(ray_dir, inv_len);
     float medium_density = tvd.c[3] * 5.0f;
     float mc[3] = {1.0f, 1.0f, 1.0f};
     if (tvd.c[3] > 0.0f) { mc[0] = tvd.c[0]; mc[1] = tvd.c[1]; mc[2] = tvd.c[2]; }
@@ -262,6 +317,7 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
     constexpr bool kLate = MODE != 0;
     float l_gl[3] = {0.0f, 0.0f, 0.0f}, l_scale = 0.0f;
     F3 l_eye{0.0f, 0.0f, 0.0f}, l_light{0.0f, 0.0f, 0.0f};
+    LightSetup l_ls{};
     int l_hl[3] = {0, 0, 0}, l_dim = 0;
     if constexpr (kLate) {
         const LateArgs la = late_args();
@@ -271,6 +327,13 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
         l_scale = la->voxel_scale;
         l_dim = la->tex_dim;
         l_light = F3{la->light_dir[0], la->light_dir[1], la->light_dir[2]};
+        if constexpr (MODE == 1 && host_light<TRAV>::value) {
+            l_ls.dir = l_light;
+            l_ls.inv = F3{la->light_inv[0], la->light_inv[1], la->light_inv[2]};
+            l_ls.push = F3{la->light_push[0], la->light_push[1], la->light_push[2]};
+            l_ls.dposf = F3{la->light_dposf[0], la->light_dposf[1], la->light_dposf[2]};
+            l_ls.dpos = I3{la->light_dpos[0], la->light_dpos[1], la->light_dpos[2]};
+        }
         l_eye = F3{lv_->cam_pos[0], lv_->cam_pos[1], lv_->cam_pos[2]};
         lo = late_out(la, lv_);
     }
@@ -343,7 +406,8 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
                 for (int k = 0; k < 3; ++k) fc[k] = fc[k] + tc[k] * sc[k] * emission * 1.0f;
             } else {
                 int lit = 1;
-                if (MODE == 1) lit = TRAV::shadow(a, tc_, add3(h.point, scale3(normal, 2e-3f)), light, h);
+                if constexpr (MODE == 1 && host_light<TRAV>::value) lit = TRAV::shadow(a, tc_, add3(h.point, scale3(normal, 2e-3f)), l_ls, h);
+                else if constexpr (MODE == 1) lit = TRAV::shadow(a, tc_, add3(h.point, scale3(normal, 2e-3f)), light, h);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     float direct = gl[k] * (float)lit * ndotl;
@@ -529,6 +593,8 @@ __global__ void math_probe_kernel(int op, const float *x, const float *y, float 
         case 7: r = (float)(int)a; break;
         case 8: r = a + b; break;
         case 9: r = a * b; break;
+        case 30: r = rcp_inrange(a); break;
+        case 31: r = sqrt_inrange(a); break;
         default: break;
     }
     out[i] = r;

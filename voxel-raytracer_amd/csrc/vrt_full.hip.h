@@ -182,15 +182,7 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
     const float sky[3] = {0.5f, 0.7f, 1.0f};
     const float kSun = 3.0f;
     uint32_t rng = rng_init(px, py, 0);
-    float u = ((float)px / (float)a.width) * 2.0f - 1.0f;
-    float v = ((float)py / (float)a.height) * 2.0f - 1.0f;
-    float view[4];
-    mat_vec(vw.inv_proj, u, v, -1.0f, 1.0f, view);
-    if (__builtin_fabsf(view[3]) > 1e-6f) { float w = view[3]; view[0] = view[0] / w; view[1] = view[1] / w; view[2] = view[2] / w; view[3] = view[3] / w; }
-    F3 vd = normalize3(F3{view[0], view[1], view[2]});
-    float wd4[4];
-    mat_vec(vw.inv_view, vd.x, vd.y, vd.z, 0.0f, wd4);
-    F3 ray_dir = normalize3(F3{wd4[0], wd4[1], wd4[2]});
+    const F3 ray_dir = primary_ray_dir(a, vw, px, py);
     const F3 ray_origin{vw.cam_pos[0], vw.cam_pos[1], vw.cam_pos[2]};
 
     int voxel_id = 0;
@@ -198,8 +190,6 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
     F3 gro = scale3(ray_origin, a.voxel_scale);
     Decoded tv = decode_leaf(vw.eye0, vw.eye1);  // medium at the eye: looked up once by the dispatcher
     float start_iof = (tv.p[0] > 0.0f && tv.p[0] < 3.0f) ? tv.p[0] : 1.0f;
-    float inv_len = 1.0f / __builtin_sqrtf(dot3(ray_dir, ray_dir));
-    ray_dir = scale3(ray_dir, inv_len);
 
     // The ray stack (comp:451) lives in private memory: 8 x 68 bytes per lane. (Holding the entry pushed last in registers
     // until it is popped -- no scratch traffic at all for opaque scenes -- was measured: the 17 extra live values push

@@ -231,12 +231,21 @@ struct TravT {
                               const View *eye = nullptr) {
         (void)ray_iof;
         F3 rp = origin;
-        float inv_len = 1.0f / __builtin_sqrtf(dot3(dir, dir));
-        dir = scale3(dir, inv_len);
         F3 inv;
-        inv.x = (__builtin_fabsf(dir.x) < 1e-8f) ? 1e20f : 1.0f / dir.x;
-        inv.y = (__builtin_fabsf(dir.y) < 1e-8f) ? 1e20f : 1.0f / dir.y;
-        inv.z = (__builtin_fabsf(dir.z) < 1e-8f) ? 1e20f : 1.0f / dir.z;
+        // hitMarching normalises the direction again and inverts it (comp:250-258). For the primary rays of a view whose
+        // prologue ran in its in-range form (View::gen_fast: `dir` is then a unit vector up to rounding) these 1/x and sqrt
+        // are in range too -- a component below 1e-8 is replaced, so the reciprocal only has to be right from there up.
+        if (eye && eye->gen_fast) {
+            dir = scale3(dir, rcp_inrange(sqrt_inrange(dot3(dir, dir))));
+            inv.x = (__builtin_fabsf(dir.x) < 1e-8f) ? 1e20f : rcp_inrange(dir.x);
+            inv.y = (__builtin_fabsf(dir.y) < 1e-8f) ? 1e20f : rcp_inrange(dir.y);
+            inv.z = (__builtin_fabsf(dir.z) < 1e-8f) ? 1e20f : rcp_inrange(dir.z);
+        } else {
+            dir = scale3(dir, 1.0f / __builtin_sqrtf(dot3(dir, dir)));
+            inv.x = (__builtin_fabsf(dir.x) < 1e-8f) ? 1e20f : 1.0f / dir.x;
+            inv.y = (__builtin_fabsf(dir.y) < 1e-8f) ? 1e20f : 1.0f / dir.y;
+            inv.z = (__builtin_fabsf(dir.z) < 1e-8f) ? 1e20f : 1.0f / dir.z;
+        }
         const I3 dpos{dir.x > 0.0f ? 1 : 0, dir.y > 0.0f ? 1 : 0, dir.z > 0.0f ? 1 : 0};
         const F3 dposf{dir.x > 0.0f ? 1.0f : 0.0f, dir.y > 0.0f ? 1.0f : 0.0f, dir.z > 0.0f ? 1.0f : 0.0f};
         const F3 sd{sign_c(dir.x), sign_c(dir.y), sign_c(dir.z)};
@@ -275,15 +284,13 @@ struct TravT {
         return hit;
     }
 
-    // notInShadow (comp:333-377); the light direction is used as given
-    static VRT_DEV int shadow(const KArgs &a, const Ctx &c, F3 origin, F3 ld, const Hit &h) {
-        F3 rp = origin, inv;
-        inv.x = (__builtin_fabsf(ld.x) < 1e-8f) ? 1e20f : 1.0f / ld.x;
-        inv.y = (__builtin_fabsf(ld.y) < 1e-8f) ? 1e20f : 1.0f / ld.y;
-        inv.z = (__builtin_fabsf(ld.z) < 1e-8f) ? 1e20f : 1.0f / ld.z;
-        const I3 dpos{ld.x > 0.0f ? 1 : 0, ld.y > 0.0f ? 1 : 0, ld.z > 0.0f ? 1 : 0};
-        const F3 dposf{ld.x > 0.0f ? 1.0f : 0.0f, ld.y > 0.0f ? 1.0f : 0.0f, ld.z > 0.0f ? 1.0f : 0.0f};
-        const F3 push{sign_c(ld.x) * 0.001f, sign_c(ld.y) * 0.001f, sign_c(ld.z) * 0.001f};
+    // notInShadow (comp:333-377); the light direction is used as given. Its reciprocal, push and signs are the same
+    // for every ray of the launch: the dispatcher made them (KArgs::light_*, handed over in `ls`).
+    static constexpr bool kHostLight = true;
+    static VRT_DEV int shadow(const KArgs &a, const Ctx &c, F3 origin, const LightSetup &ls, const Hit &h) {
+        F3 rp = origin;
+        const F3 ld = ls.dir, inv = ls.inv, push = ls.push, dposf = ls.dposf;
+        const I3 dpos = ls.dpos;
         F3 pf;
         I3 mp;
         floor_both(rp, pf, mp);
@@ -306,7 +313,20 @@ struct TravT {
         } while (go);
         return lit;
     }
+    // the same from the direction alone (the full path tracer's call)
+    static VRT_DEV int shadow(const KArgs &a, const Ctx &c, F3 origin, F3 ld, const Hit &h) {
+        LightSetup ls;
+        ls.dir = ld;
+        ls.inv.x = (__builtin_fabsf(ld.x) < 1e-8f) ? 1e20f : 1.0f / ld.x;
+        ls.inv.y = (__builtin_fabsf(ld.y) < 1e-8f) ? 1e20f : 1.0f / ld.y;
+        ls.inv.z = (__builtin_fabsf(ld.z) < 1e-8f) ? 1e20f : 1.0f / ld.z;
+        ls.dpos = I3{ld.x > 0.0f ? 1 : 0, ld.y > 0.0f ? 1 : 0, ld.z > 0.0f ? 1 : 0};
+        ls.dposf = F3{ld.x > 0.0f ? 1.0f : 0.0f, ld.y > 0.0f ? 1.0f : 0.0f, ld.z > 0.0f ? 1.0f : 0.0f};
+        ls.push = F3{sign_c(ld.x) * 0.001f, sign_c(ld.y) * 0.001f, sign_c(ld.z) * 0.001f};
+        return shadow(a, c, origin, ls, h);
+    }
 };
+
 
 using Trav = TravT<true>;       // modes 0, 1 when the eye is in empty space (else the dispatcher takes v3)
 using TravAny = TravT<false>;   // the full path tracer
