@@ -916,6 +916,12 @@ def test_ray_generation_tables_in_range_math_and_host_light_setup(ctx, V, O, pro
     y = np.concatenate([y, np.float32([2.0 ** -96, 1.0, 2.0, 3.0, 4.0, 0.99999994, 1.0000001, 3.4028235e38, 2.0 ** -95, 2.0 ** -94])]).astype(np.float32)
     got = ctx.debug_math(31, y, y)
     same_bits(got, np.sqrt(y), y, "sqrt_inrange vs sqrt")
+    # x / PI with the denominator known at compile time: every mantissa at one exponent, random values over the range it is
+    # used in (2^-100 .. 2^96), zero
+    z = np.concatenate([(np.arange(1 << 23, dtype=np.uint32) | np.uint32(0x3f800000)).view(np.float32),
+                        np.exp2(rng.uniform(-100.0, 96.0, size=400000)).astype(np.float32), np.float32([0.0, 1.0, 3.14159265359, 2.0 ** 96])])
+    got = ctx.debug_math(32, z, z)
+    same_bits(got, z / np.float32(3.14159265359), z, "div_pi_inrange vs x / PI")
 
     tex, dim = product_scenes["dragon"]
     ctx.upload_octree(tex, dim)

@@ -564,6 +564,11 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
         a.light_dposf[i] = d > 0.0f ? 1.0f : 0.0f;
     }
     for (int i = 0; i < 4; ++i) a.global_light[i] = c->params.global_light[i];
+    // |globalLight|, |lightDir| <= 2^30: direct (light * n.l) * colour * throughput (starts as the light) stays below 2^90 < 2^97,
+    // where x / PI needs no range scaling
+    a.shade_fast = 1;
+    for (int i = 0; i < 3; ++i)
+        if (!(fabsf(a.global_light[i]) <= 1073741824.0f) || !(fabsf(a.light_dir[i]) <= 1073741824.0f)) a.shade_fast = 0;
     a.tex_dim = (int)c->info.tex_dim;
     a.width = width;
     a.height = height;

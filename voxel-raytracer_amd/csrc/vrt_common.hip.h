@@ -65,6 +65,7 @@ struct KArgs {
     // with the shader's operations -- 1/d or 1e20, sign * 1e-3, d > 0 -- instead of 70 vector instructions per wave
     float light_inv[3], light_push[3], light_dposf[3];
     int light_dpos[3];
+    int shade_fast;           // globalLight and lightDir are finite and at most 2^30: the shading quotients x / PI are in range (div_pi_inrange())
     int highlighted[3];
     int tex_dim;
     int width, height;
@@ -135,6 +136,19 @@ VRT_DEV float sqrt_inrange(float x) {
     const float below = __uint_as_float(__float_as_uint(s) - 1u), above = __uint_as_float(__float_as_uint(s) + 1u);
     const float r = (0.0f >= __builtin_fmaf(-below, s, x)) ? below : s;
     return (0.0f < __builtin_fmaf(-above, s, x)) ? above : r;
+}
+// x / 3.14159265359f (comp:589, the Lambert term) for 0 <= x < 2^97: the same sequence with its denominator known when
+// the code is compiled -- five fused operations. y is the refined reciprocal the sequence would compute from v_rcp_f32;
+// the sequence's result is the correctly rounded quotient for any starting value within an ulp of 1/d, so the correctly
+// rounded 1/PI serves as one. Below 2^-103 the hardware form rescales and this one may differ in the last bit: such an
+// x is a colour term that rounds to 0 in rgba8 either way. (vrt_debug_math op 32: all 2^23 mantissas and random exponents.)
+VRT_DEV float div_pi_inrange(float x) {
+    constexpr float kD = 3.14159265359f;
+    constexpr float kY0 = 0.318309873342514038f;   // 0x3ea2f983 = RN(1 / kD)
+    const float y = __builtin_fmaf(__builtin_fmaf(-kD, kY0, 1.0f), kY0, kY0);
+    float q = x * y;
+    q = __builtin_fmaf(__builtin_fmaf(-kD, q, x), y, q);
+    return __builtin_fmaf(__builtin_fmaf(-kD, q, x), y, q);
 }
 VRT_DEV F3 normalize3_inrange(F3 a) { return scale3(a, rcp_inrange(sqrt_inrange(dot3(a, a)))); }
 VRT_DEV float sign_c(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
@@ -318,7 +332,7 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
     float l_gl[3] = {0.0f, 0.0f, 0.0f}, l_scale = 0.0f;
     F3 l_eye{0.0f, 0.0f, 0.0f}, l_light{0.0f, 0.0f, 0.0f};
     LightSetup l_ls{};
-    int l_hl[3] = {0, 0, 0}, l_dim = 0;
+    int l_hl[3] = {0, 0, 0}, l_dim = 0, l_shade_fast = 0;
     if constexpr (kLate) {
         const LateArgs la = late_args();
         const LateView lv_ = late_view();
@@ -326,6 +340,7 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
         for (int k = 0; k < 3; ++k) { l_gl[k] = la->global_light[k]; l_hl[k] = la->highlighted[k]; }
         l_scale = la->voxel_scale;
         l_dim = la->tex_dim;
+        l_shade_fast = la->shade_fast;
         l_light = F3{la->light_dir[0], la->light_dir[1], la->light_dir[2]};
         if constexpr (MODE == 1 && host_light<TRAV>::value) {
             l_ls.dir = l_light;
@@ -343,6 +358,7 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
     const float gl[3] = {gl_(0), gl_(1), gl_(2)};
     const auto scale_ = [&]() { if constexpr (kLate) return l_scale; else return a.voxel_scale; };
     const auto dim_ = [&]() { if constexpr (kLate) return l_dim; else return a.tex_dim; };
+    const bool shade_fast = (kLate ? l_shade_fast : a.shade_fast) != 0;
     const auto eye_ = [&]() { if constexpr (kLate) return l_eye; else return ray_origin; };  // ray_origin; gro = ray_origin * u_voxelScale
     const auto light_ = [&]() { if constexpr (kLate) return l_light; else return F3{a.light_dir[0], a.light_dir[1], a.light_dir[2]}; };
     float tc[3] = {gl[0], gl[1], gl[2]};
@@ -362,15 +378,15 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
         float dist_in_medium = 0.0f;
         if (medium_density > 0.0f) dist_in_medium = 0.0f + len3(sub3(hpw, scale3(eye_(), scale_()))) / scale_();
         Decoded hv = decode_leaf(h.h0, h.h1);
-        Decoded lv = decode_leaf(h.p0, h.p1);
         if (hv.c[3] <= 0.0f) { hv.p[0] = 1.0f; hv.p[1] = 0.0f; hv.p[2] = 0.0f; }
-        if (lv.c[3] <= 0.0f) {
-            if (start_iof > 0.0f) { lv.p[0] = 0.0f; lv.p[1] = 0.0f; lv.p[2] = 0.0f; }
-            else { lv.p[0] = 1.0f; lv.p[1] = 0.0f; lv.p[2] = 0.0f; }
+        float sc[4] = {hv.c[0], hv.c[1], hv.c[2], hv.c[3]};
+        // surfaceColor = hitVoxel.color.a > 0 ? hitVoxel.color : lastVoxel.color (comp:505-507): the previous voxel is
+        // decoded only in waves where some lane hit a voxel of alpha 0 (a phantom leaf); of its fields only the colour is
+        // read on this path
+        if (__builtin_amdgcn_ballot_w64((h.h0 >> 24) == 0u) != 0ull) {
+            const Decoded lv = decode_leaf(h.p0, h.p1);
+            if (!(hv.c[3] > 0.0f)) { sc[0] = lv.c[0]; sc[1] = lv.c[1]; sc[2] = lv.c[2]; sc[3] = lv.c[3]; }
         }
-        float sc[4];
-        if (hv.c[3] > 0.0f) { sc[0] = hv.c[0]; sc[1] = hv.c[1]; sc[2] = hv.c[2]; sc[3] = hv.c[3]; }
-        else { sc[0] = lv.c[0]; sc[1] = lv.c[1]; sc[2] = lv.c[2]; sc[3] = lv.c[3]; }
         if (dist_in_medium > 1e-6f && medium_density > 0.0f) {  // comp:512-516
             float kk = -medium_density * dist_in_medium;
 #pragma unroll
@@ -390,7 +406,9 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
             const int dim = dim_();
             int lin = h.map.x + dim * (h.map.y + dim * h.map.z);
             voxel_id = lin * 6 + face_index(h.axis, h.n);
-            pixel_dist = (int)len3(sub3(hpw, eye_()));
+            // (int)sqrt: the in-range form is the full one from 2^-96 up and returns 0 for 0; between them both round to 0
+            const F3 dv = sub3(hpw, eye_());
+            pixel_dist = (int)sqrt_inrange(dot3(dv, dv));
         }
         if (sc[3] < 1.0f) {  // translucent first hit: direct-lit fallback (comp:548-553)
 #pragma unroll
@@ -411,7 +429,8 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     float direct = gl[k] * (float)lit * ndotl;
-                    fc[k] = fc[k] + direct * sc[k] * tc[k] * 1.0f / kPI;
+                    const float num = direct * sc[k] * tc[k] * 1.0f;
+                    fc[k] = fc[k] + (shade_fast ? div_pi_inrange(num) : num / kPI);
                 }
             }
         }
@@ -595,6 +614,7 @@ __global__ void math_probe_kernel(int op, const float *x, const float *y, float 
         case 9: r = a * b; break;
         case 30: r = rcp_inrange(a); break;
         case 31: r = sqrt_inrange(a); break;
+        case 32: r = div_pi_inrange(a); break;
         default: break;
     }
     out[i] = r;
