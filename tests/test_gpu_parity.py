@@ -142,6 +142,12 @@ def test_degenerate_inputs(ctx, V, O, product_scenes):
     for pose, (W, H) in [((34.0, 60.0, 34.0, -90.0, 0.0), (64, 36)), ((20.0, 30.0, 20.0, 0.0, 0.0), (40, 40)),
                          ((63.5, 2000.0, 30.5, -90.0, -89.0), (32, 32)),   # camera outside the world (above)
                          ((-2000.5, 50.5, 30.5, 0.0, 0.0), (32, 18)),      # outside, looking in along +x
+                         # outside, the first step lands outside too but within 1024 units of the eye (found by tools/fuzz_parity.py
+                         # seed 211: the v4 walk took such a point for one of wide root 0)
+                         ((877.630258097967, 413.60274114898647, 1499.3121964738943, 32.390759674626054, 37.50787468408298), (47, 53)),
+                         ((-919.1504641258679, -530.0652491118379, 1599.2008229520852, -90.0, -45.0), (96, 47)),
+                         ((492.5792800470553, 1058.786681235461, -596.7419040459511, -180.0, 0.0), (46, 10)),
+                         ((1102.7347442281894, 349.15493098196606, 58.2267500913418, 45.0, 87.46694058563853), (32, 19)),
                          ((63.5, 60.5, 140.5, -90.0, -10.0), (1, 1)), ((63.5, 60.5, 140.5, -90.0, -10.0), (13, 7))]:
         cam = _setup(ctx, V, tex, dim, pose, W, H)
         for mode in (0, 1, 2):

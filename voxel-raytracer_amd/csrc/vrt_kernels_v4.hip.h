@@ -93,7 +93,8 @@ struct TravT {
     // octreeFind (comp:137-220): the deepest octree node containing p (= floor of a ray position, pf the same as
     // floats), through the wide layout.
     // kGo: the answer came from a cell (f set). kDone: from the record walk above the wide roots (f set).
-    // kOutside: p is outside the world (comp:143-145): f untouched.
+    // kOutside: p is outside the world (comp:143-145): f untouched -- and w then refers to p as if it were a point of wide
+    // root 0: a caller that goes on after kOutside (only the first lookups of march() and shadow() do) must reset(w).
     //
     // A lookup that has left its anchor (or has none) takes the one conditional block of the march loop: world-bounds
     // test, then wide root 0 when the point lies in its cube -- where the descent from the octree root would arrive
@@ -168,21 +169,43 @@ struct TravT {
     // with m = (ty < tz ? ty : tz) the first test is tx < m, and tStep = min(tx, min(ty, tz)) is the tMax of that axis.
     // The vector port is what binds this kernel (a v_cndmask costs 4.4 ticks of it, a v_add_f32 2.6, scalar mask
     // arithmetic none): the push (comp:300-304) is added under the axis' lane mask instead of being selected per axis.
+    // The two comparisons and everything that hangs on them are written out: the compiler computes each condition AND
+    // its negation with a v_cmp of its own (four per step, 4.4 ticks each) and branches around every masked add. Here:
+    // two v_cmp into scalar mask pairs, two v_cndmask on them, three adds under exec = the axis' lanes (an add with no
+    // lane enabled costs its issue slot and nothing else). gfx950 needs two wait states between a VALU instruction that
+    // writes a scalar register and a VALU instruction that reads it as a mask (s_nop 1); scalar instructions interlock.
     struct Axis { bool x, yz; };   // exit axis: x ? 0 : (yz ? 1 : 2)
     static VRT_DEV Axis dda_step(F3 &rp, F3 dir, F3 inv, F3 push, F3 plane) {
         const float tx = (plane.x - rp.x) * inv.x;
         const float ty = (plane.y - rp.y) * inv.y;
         const float tz = (plane.z - rp.z) * inv.z;
-        const bool yz = ty < tz;
-        const float m = yz ? ty : tz;
-        const bool ax = tx < m;
-        const float t = ax ? tx : m;
+        uint64_t mx, myz;
+        float t;
+        asm("v_cmp_lt_f32_e64 %[myz], %[ty], %[tz]\n\t"
+            "s_nop 1\n\t"
+            "v_cndmask_b32_e64 %[t], %[tz], %[ty], %[myz]\n\t"     // m = ty < tz ? ty : tz
+            "v_cmp_lt_f32_e64 %[mx], %[tx], %[t]\n\t"
+            "s_nop 1\n\t"
+            "v_cndmask_b32_e64 %[t], %[t], %[tx], %[mx]"             // t = tx < m ? tx : m
+            : [t] "=&v"(t), [mx] "=&s"(mx), [myz] "=&s"(myz)
+            : [tx] "v"(tx), [ty] "v"(ty), [tz] "v"(tz));
         float rx = rp.x + dir.x * t, ry = rp.y + dir.y * t, rz = rp.z + dir.z * t;
-        if (ax) asm volatile("v_add_f32 %0, %1, %0" : "+v"(rx) : "v"(push.x));
-        else if (yz) asm volatile("v_add_f32 %0, %1, %0" : "+v"(ry) : "v"(push.y));
-        else asm volatile("v_add_f32 %0, %1, %0" : "+v"(rz) : "v"(push.z));
+        uint64_t save, rest;
+        asm volatile("s_mov_b64 %[save], exec\n\t"
+                     "s_mov_b64 exec, %[mx]\n\t"                    // a v_cmp result holds no lane that is not enabled
+                     "v_add_f32_e32 %[rx], %[px], %[rx]\n\t"
+                     "s_andn2_b64 %[rest], %[save], %[mx]\n\t"
+                     "s_and_b64 exec, %[rest], %[myz]\n\t"
+                     "v_add_f32_e32 %[ry], %[py], %[ry]\n\t"
+                     "s_andn2_b64 exec, %[rest], %[myz]\n\t"
+                     "v_add_f32_e32 %[rz], %[pz], %[rz]\n\t"
+                     "s_mov_b64 exec, %[save]"
+                     : [rx] "+v"(rx), [ry] "+v"(ry), [rz] "+v"(rz), [save] "=&s"(save), [rest] "=&s"(rest)
+                     : [mx] "s"(mx), [myz] "s"(myz), [px] "v"(push.x), [py] "v"(push.y), [pz] "v"(push.z)
+                     : "scc");
         rp.x = rx; rp.y = ry; rp.z = rz;
-        return Axis{ax, yz};
+        // the masks as per-lane conditions again: no instruction, the compiler keeps such conditions as lane masks
+        return Axis{__builtin_amdgcn_inverse_ballot_w64(mx), __builtin_amdgcn_inverse_ballot_w64(myz)};
     }
 
     static VRT_DEV void floor_both(F3 rp, F3 &pf, I3 &p) {
@@ -267,7 +290,9 @@ struct TravT {
                            (__builtin_floorf(pf.z * inv_side) + dposf.z) * side};
         } else {
             reset(w);
-            if (find(a, c, mp, pf, dpos, dposf, w, cur) == kOutside) cur.plane = world_planes(a, dpos);
+            // an eye outside the world: find() has noted that point as the walk's reference, and the next point -- still
+            // outside, a few units on -- would pass for a point of wide root 0: no current node again
+            if (find(a, c, mp, pf, dpos, dposf, w, cur) == kOutside) { cur.plane = world_planes(a, dpos); reset(w); }
         }
         int axis = 2;
         uint32_t px = 0u, py = 85u | (1u << 23);
@@ -298,7 +323,7 @@ struct TravT {
         w.node = h.r_node; w.cs = (uint32_t)h.r_s; w.anode = h.r_anode; w.acs = (uint32_t)h.r_as; w.last = h.r_last;
         Found v;
         v.x = 0u; v.y = 85u | (1u << 23); v.plane = F3{0.0f, 0.0f, 0.0f};
-        if (find(a, c, mp, pf, dpos, dposf, w, v) == kOutside) v.plane = world_planes(a, dpos);
+        if (find(a, c, mp, pf, dpos, dposf, w, v) == kOutside) { v.plane = world_planes(a, dpos); reset(w); }   // as in march()
         int lit = 1, i = 0;
         bool go;
         do {
