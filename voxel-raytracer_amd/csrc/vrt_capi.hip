@@ -500,9 +500,10 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
         // and no extra spills measured 8-10 % faster than the unconstrained 105-VGPR build) and, as baselines, for
         // the other two in one shape each
         v.use_lds = false; v.tw = 8; v.lds_cap = 0; v.blocks_per_cu = 0;
-        // the default takes the v3 traversal here: with the v4 loops the full path tracer's 96-register build spills and
-        // measured 10 % slower (profiles/r02_variant_sweep.jsonl); variants 21-24 select it explicitly in an A/B build
-        if (v.trav == 4 && (c->variant == 0 || !VRT_AB)) v.trav = 3;
+        // the default takes the v4 traversal here too (one march loop, for rays that start in any medium: 96 registers
+        // without spills; 9 % faster than v3, profiles/r02_f_full_shader_v4_ab.jsonl); variant 20 is v3, and so is the
+        // two-kernel experiment of an A/B build
+        if (v.trav == 4 && VRT_AB && c->full_split) v.trav = 3;
         if (v.trav >= 3) { v.block = (v.block == 64 || !VRT_AB) ? 64 : 256; v.wpe = 5; }
         else { v.block = 256; v.wpe = 1; }
     } else if (mode == VRT_MODE_PRIMARY_SHADOW && c->variant == 20 && v.trav == 3) {
@@ -690,9 +691,9 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     } else
 #endif
     if (mode == VRT_MODE_FULL) {
-        if (v.trav == 3 && v.block == 64) e = launch_sched<2, vrt::v3::Trav, 8, 64, 5>(a, vs, (int)grid, 0, s, ev0, ev1);
+        if (v.trav == 4) e = launch_sched<2, vrt::v4::TravAny, 8, 64, 5>(a, vs, (int)grid, 0, s, ev0, ev1);
+        else if (v.trav == 3 && v.block == 64) e = launch_sched<2, vrt::v3::Trav, 8, 64, 5>(a, vs, (int)grid, 0, s, ev0, ev1);
 #if VRT_AB
-        else if (v.trav == 4) e = launch_sched<2, vrt::v4::TravAny, 8, 64, 5>(a, vs, (int)grid, 0, s, ev0, ev1);
         else if (v.trav == 3) e = launch_sched<2, vrt::v3::Trav, 8, 256, 5>(a, vs, (int)grid, 0, s, ev0, ev1);
 #endif
         else if (v.trav == 2) e = launch_one<2, vrt::v2::Trav<false>, 8, 256, 1>(a, vs, (int)grid, 0, s);

@@ -67,7 +67,7 @@ VRT_DEV uint32_t cell4_y(uint32_t w0, uint32_t w1, uint32_t tp1) {
 
 // EYE85: the caller guarantees that every march() starts in refraction byte 85 (1.0) -- the primary rays of views whose
 // eye is in empty space, which the dispatcher checks (it has the eye's voxel) -- so the kernel holds one march loop and
-// its registers; otherwise march() chooses between the two loops per wave (the full path tracer's secondary rays).
+// its registers; otherwise march() runs the loop that takes a ray's own starting medium (the full path tracer).
 template <bool EYE85>
 struct TravT {
     static constexpr bool kStagesLds = false;
@@ -296,10 +296,10 @@ struct TravT {
         }
         int axis = 2;
         uint32_t px = 0u, py = 85u | (1u << 23);
-        // wave-uniform choice of the loop: all lanes start in refraction 1.0 (every primary ray of a view whose eye is in
-        // empty space; most secondary rays)
         bool hit;
-        if (EYE85 || __builtin_amdgcn_ballot_w64(iof_byte != 85u) == 0ull) hit = march_loop<true>(a, c, rp, dir, inv, push, dpos, dposf, w, cur, iof_byte, axis, px, py, mp);
+        // one loop per instantiation: choosing between the two per wave (all lanes in refraction 1.0 or not) made the full
+        // path tracer hold both and spill 16 registers at its five waves per SIMD
+        if constexpr (EYE85) hit = march_loop<true>(a, c, rp, dir, inv, push, dpos, dposf, w, cur, iof_byte, axis, px, py, mp);
         else hit = march_loop<false>(a, c, rp, dir, inv, push, dpos, dposf, w, cur, iof_byte, axis, px, py, mp);
         const float n = -comp(sd, axis);
         h.axis = axis; h.n = n;
