@@ -187,6 +187,14 @@ def load_world(V, name):
     return wld
 
 
+# Untimed frames before the W warm-up steps of the headline region, to take the GPU out of its idle power state: a
+# default driver run (W = 5, K = 20) is 1.6 ms of GPU work in all, and the kernel keeps getting faster for ~30 ms after
+# the first launch (profiles/r02_f_preroll.txt: 0.0638 ms per launch right away, 0.0612 after 64 frames, 0.0582 after
+# 512, 0.0578 after 4096). Disclosed in the JSON line (config.preroll_launches), with the region WITHOUT them beside it
+# (`cold_start`); VRT_BENCH_PREROLL=0 makes that region the headline.
+PREROLL = int(os.environ.get("VRT_BENCH_PREROLL", "512"))
+
+
 def issue_roofline(args, kernel_ms_mean, rows_local, H):
     """The limiter the PMC passes point at: instruction issue. Instructions per launch (vector and scalar) come from the
     committed PMC pass of this exact workload and the SIMD time each kind costs from tools/micro/valu_rate
@@ -284,8 +292,9 @@ def main():
     plan = shd.ShardPlan(W, H, args.tile_rows, rank, world)
     n_streams = args.streams or (1 if world == 1 else 4)
 
-    def timed_region(gather_mode, profile):
-        """W warm-up frames, fence, K timed frames, fence; MAX over ranks. Returns (seconds, pipeline, kernel ms samples)."""
+    def timed_region(gather_mode, profile, preroll=0):
+        """[preroll untimed frames,] W warm-up frames, fence, K timed frames, fence; MAX over ranks.
+        Returns (seconds, pipeline, kernel ms samples)."""
         pipe = shd.FramePipeline(plan, dev, stage_through_host=via_host, gather=gather_mode, streams=n_streams)
 
         def step():
@@ -300,6 +309,8 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize(dev)
 
+        for _ in range(preroll):   # see PREROLL
+            step()
         for _ in range(args.warmup):
             step()
         fence()
@@ -321,7 +332,16 @@ def main():
         torch.cuda.synchronize(dev)
         return el, pipe, ms
 
-    elapsed, pipe, kernel_ms = timed_region(gather, not args.no_kernel_events)
+    # the contract's region as the first GPU work of the process (W warm-up frames, K timed ones: 1.6 ms of GPU time at the
+    # driver's W = 5, K = 20, while the clocks are still coming up), reported as `cold_start`; then the headline region
+    # behind PREROLL untimed frames
+    cold = None
+    if PREROLL > 0:
+        ec, pipe_c, _ = timed_region(gather, False)
+        cold = {"value": round(W * H * args.steps / ec / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(ec / args.steps * 1e3, 5),
+                "what": "the same W warm-up + K timed frames as the process's first GPU work, no untimed frames before them"}
+        del pipe_c
+    elapsed, pipe, kernel_ms = timed_region(gather, not args.no_kernel_events, PREROLL)
 
     # several GPUs: SURVEY 8(e) asks for the rate with AND without the per-frame gather: the other mode, same K frames
     other = None
@@ -524,11 +544,12 @@ def main():
                            "mappings of rank 0's frame buffers (xGMI peer stores, stream flags, four slots)"
                            if delivery_used == "peer_store_rank0" else delivery),
                        "gather": gather, "delivery": delivery_used, "streams": n_streams, "tile_scheduling_period": args.sched_period,
-                       "variant": args.variant, "ray_tables": not args.no_ray_tables, "collective_backend": args.backend if world > 1 else None,
+                       "variant": args.variant, "ray_tables": not args.no_ray_tables, "preroll_launches": PREROLL, "collective_backend": args.backend if world > 1 else None,
                        "launcher": launcher},
             "roofline": roofline,
             "issue_roofline": issue,
             "pixels_match_oracle_golden": check,
+            "cold_start": cold,
             ("sharded_resident" if gather == "frame" else "every_frame_delivered"): other,
             "rccl_gather_every_frame": rccl_frame,
             "peer_delivery": peer or None,

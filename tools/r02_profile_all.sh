@@ -7,6 +7,7 @@ mkdir -p "$OUT"
 cd "$REPO"
 python3 bench.py --steps 200 --warmup 20 > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_n1_driver_shape.json" 2>> "$OUT/bench_n1.err"
+VRT_BENCH_PREROLL=0 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_n1_driver_shape_no_preroll.json" 2>> "$OUT/bench_n1.err"
 python3 bench.py --steps 200 --warmup 20 --extras --no-cpu-baseline > "$OUT/bench_n1_extras.json" 2>> "$OUT/bench_n1.err"
 : > "$OUT/other_configs.jsonl"
 for cfg in "--mode primary_shadow" "--mode full" "--map terrain" "--map terrain --mode primary_shadow" "--map monu9 --width 1280 --height 720" \

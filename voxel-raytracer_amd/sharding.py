@@ -84,7 +84,10 @@ def gather_frame(plan, local, gathered, store, index, group=None, stage_through_
         src = local
     if plan.rank != 0:
         return
-    store.index_copy_(0, index, src.view(plan.world * 3 * plan.rows_max, plan.width))
+    if plan.world == 1:   # one rank: its buffer holds the rows in frame order, the scatter is the identity: a plain copy
+        store[:3 * plan.height].copy_(src.view(3 * plan.height, plan.width))
+    else:
+        store.index_copy_(0, index, src.view(plan.world * 3 * plan.rows_max, plan.width))
 
 
 class FramePipeline:
