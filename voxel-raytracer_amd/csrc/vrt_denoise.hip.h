@@ -141,6 +141,7 @@ __device__ __forceinline__ int slot(const int col) {
     return (col % PX) * (kSpanX / PX) + col / PX;
 }
 
+#ifndef VRT_DENOISE_MASKED_TAP   // a 0/1 mask multiplied in: compare, select, two packed fmas
 __device__ __forceinline__ void tap(const f4 rec, const int cid, f2 &rg, f2 &bc, const bool in_range = true) {
     const float m = (__float_as_int(rec.w) == cid && in_range) ? 1.0f : 0.0f;
     const f2 mm = {m, m};
@@ -149,6 +150,31 @@ __device__ __forceinline__ void tap(const f4 rec, const int cid, f2 &rg, f2 &bc,
     rg = __builtin_elementwise_fma(mm, c01, rg);
     bc = __builtin_elementwise_fma(mm, c2, bc);
 }
+#else
+// Tried in round 2 and measured SLOWER (kept for the record, -DVRT_DENOISE_MASKED_TAP): the conditional add as what it
+// is -- the comparison's lane mask becomes exec for two packed adds, which saves the v_cndmask (as dear as a packed add,
+// profiles/r02_valu_rate.txt) and turns the fmas into adds: 13.2 instead of 17.6 ticks of vector issue per tap and
+// pixel. Same pixels, but 1080p dragon 0.463 ms against 0.342 (0.449 / 0.285 with feedback scheduling), monu9 720p
+// 0.222 / 0.190, nature 4K 0.230 / 0.178 (profiles/r02_f_denoise_masked_tap.txt): every tap now hangs on a scalar ->
+// vector hand-over of exec, and this kernel runs two waves per SIMD (70 KB of LDS per workgroup) -- too few to hide it.
+// The mask-multiply form is a pure stream of independent vector instructions, which is what so few waves need.
+__device__ __forceinline__ void tap(const f4 rec, const int cid, f2 &rg, f2 &bc, const bool in_range = true) {
+    // two ballots and a scalar AND: the ballot of `a && b` is lowered through a select and a second compare
+    const uint64_t m = __builtin_amdgcn_ballot_w64(__float_as_int(rec.w) == cid) & __builtin_amdgcn_ballot_w64(in_range);
+    const f2 c01 = {rec.x, rec.y};
+    const f2 c2 = {rec.z, 1.0f};
+    uint64_t saved;
+    // not volatile: exec is back to what it was when the statement ends, and a volatile statement keeps the row's LDS reads
+    // from being hoisted over it
+    asm("s_and_saveexec_b64 %[saved], %[m]\n\t"
+                 "v_pk_add_f32 %[rg], %[rg], %[c01]\n\t"
+                 "v_pk_add_f32 %[bc], %[bc], %[c2]\n\t"
+                 "s_mov_b64 exec, %[saved]"
+                 : [rg] "+v"(rg), [bc] "+v"(bc), [saved] "=&s"(saved)
+                 : [m] "s"(m), [c01] "v"(c01), [c2] "v"(c2)
+                 : "scc");
+}
+#endif
 
 // RM is the largest radius among the wave's summed pixels, DELTA (wave-uniform) at least RM - the smallest.
 // Tap u of a row (x = u - RM relative to pixel 0) can only matter to pixel k when k <= u <= k + 2RM, and it
