@@ -86,7 +86,11 @@ struct TravT {
     static VRT_DEV uint2 load_cell(const KArgs &a, uint32_t node, uint32_t cs, I3 p) {
         const uint32_t bx = __builtin_amdgcn_ubfe((uint32_t)p.x, cs, 2u), by = __builtin_amdgcn_ubfe((uint32_t)p.y, cs, 2u),
                        bz = __builtin_amdgcn_ubfe((uint32_t)p.z, cs, 2u);
-        const uint32_t off = ((((bx << 2) | by) << 2 | bz) << 3) | node;
+        // node + (((bx << 2 | by) << 2 | bz) << 3) as three v_lshl_add_u32 (the compiler spreads it over four instructions)
+        uint32_t off;
+        asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(bx), "v"(by));
+        asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(off), "v"(bz));
+        asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(off) : "v"(off), "v"(node));
         return *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(a.cells4) + off);
     }
 
