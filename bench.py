@@ -285,6 +285,8 @@ def main():
     ctx.set_variant(args.variant)
     if args.no_ray_tables:
         ctx.set_ray_tables(False)
+    if os.environ.get("VRT_BENCH_NO_ROOT0_ONLY"):
+        ctx.set_root0_only(False)   # A/B: rays that leave wide root 0 walk the empty octants' records
     ctx.set_tile_scheduling(args.sched_period)
     ctx.upload_octree(tex, dim)
     ctx.set_camera(ip, iv, cp)

@@ -982,6 +982,33 @@ def test_ray_generation_tables_in_range_math_and_host_light_setup(ctx, V, O, pro
         ctx.set_params(ctx.default_params())
 
 
+def test_rays_leaving_the_only_occupied_cube(ctx, V, O, product_scenes):
+    """KArgs::root0_only (the dispatcher found the tree empty outside wide root 0): a ray that has been inside that cube
+    and left it misses at once instead of walking the empty octants' records. Same frames with the shortcut, without it
+    (vrt_debug_set_root0_only(0)) and from the oracle, for eyes inside the cube, in another octant of the world (negative
+    coordinates: those rays must still find their way IN), on the cube's faces and outside the world; all modes."""
+    tex, dim = product_scenes["dragon"]
+    ctx.upload_octree(tex, dim)
+    ctx.set_params(ctx.default_params())
+    poses = [(63.5, 60.5, 140.5, -90.0, -10.0), (63.5, 60.5, -140.5, 90.0, -10.0), (-40.5, 30.5, -60.5, 40.0, 5.0),
+             (-200.5, 300.5, 64.5, 0.0, -45.0), (0.0, 40.0, 64.0, 0.0, 0.0), (63.5, 1023.5, 64.5, -90.0, -89.0),
+             (64.5, 50.5, 1500.5, -90.0, 0.0), (500.5, -1500.5, 500.5, 45.0, 60.0)]
+    try:
+        for pose in poses:
+            for (W, H) in [(64, 40), (33, 17)]:
+                ip, iv, cp, _ = V.camera_block(pose[:3], pose[3], pose[4], W, H)
+                ctx.set_camera(ip, iv, cp)
+                for mode in (0, 1, 2):
+                    ref_rgba, ref_id, _ = _oracle_frame(O, tex, dim, (ip, iv, cp), W, H, mode)
+                    for on in (True, False):
+                        ctx.set_root0_only(on)
+                        rgba, idd = ctx.dispatch(W, H, mode)
+                        _assert_same(rgba, ref_rgba, f"pose {pose} {W}x{H} mode {mode} shortcut {on} rgba8")
+                        _assert_same(idd, ref_id, f"pose {pose} {W}x{H} mode {mode} shortcut {on} id/dist")
+    finally:
+        ctx.set_root0_only(True)
+
+
 def test_fused_frame_call_equals_dispatch_then_display_pass(ctx, V, product_scenes):
     """vrt_dispatch_frame keeps the two intermediate images on the device; all three results must equal the
     two-call route, at a size off every tile edge."""

@@ -181,6 +181,7 @@ def hip_lib():
         L.vrt_multi_stream.argtypes = [C.c_void_p]
         L.vrt_debug_set_full_split.argtypes = [C.c_void_p, C.c_int]
         L.vrt_debug_set_ray_tables.argtypes = [C.c_void_p, C.c_int]
+        L.vrt_debug_set_root0_only.argtypes = [C.c_void_p, C.c_int]
         L.vrt_debug_set_bounce.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.vrt_version.restype = C.c_char_p
         L.vrt_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -648,6 +649,10 @@ class Context:
     @property
     def stream(self):
         return self._L.vrt_stream(self._h)
+
+    def set_root0_only(self, on):
+        """A/B: False = rays that leave wide root 0 always walk the records of the octants around it"""
+        self._chk(hip_lib().vrt_debug_set_root0_only(self._h, 1 if on else 0))
 
     def set_ray_tables(self, on):
         """A/B: False = every launch runs the shader's own ray-generation prologue (no per-projection tables)"""

@@ -182,6 +182,7 @@ struct vrt_ctx {
     };
     std::vector<RayTable> ray_tables;
     uint64_t ray_tick = 0;
+    bool root0_only_on = true;                   // vrt_debug_set_root0_only(0): never tell the kernels that the world is empty outside wide root 0
     bool ray_tables_on = true;                   // vrt_debug_set_ray_tables(0): always the shader's own prologue (A/B, tests)
     const uint32_t *dbg_group_order = nullptr;  // vrt_debug_set_tile_order: caller-owned buffers instead of the scheduler's
     uint32_t *dbg_tile_cost = nullptr;
@@ -588,6 +589,22 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     a.root_table = c->d_roots;
     a.root0_node = a.n_roots ? c->wide.roots[0].node : 0u;
     a.root0_shift = a.n_roots ? c->wide.roots[0].shift : 0;
+    a.root0_only = 0;
+    if (a.n_roots == 1u && c->root0_only_on) {
+        // from the octree root down to wide root 0's record every node must have exactly one child, an internal one: then
+        // all else is absent children, i.e. empty space (the shipped maps: the root's only child is the octant [0, 1024)^3)
+        uint32_t cur = 0;
+        const uint32_t target = c->wide.roots[0].record;
+        bool chain = true;
+        for (int depth = 0; chain && cur != target && depth < 16; ++depth) {
+            if (cur >= c->host_records.size()) { chain = false; break; }
+            const vrt::Record &r = c->host_records[cur];
+            const uint32_t mask = r.w0 & 0xffu, leaves = (r.w0 >> 8) & 0xffu;
+            chain = mask != 0u && (mask & (mask - 1u)) == 0u && (leaves & mask) == 0u;
+            cur = r.w1;
+        }
+        a.root0_only = (chain && cur == target) ? 1 : 0;
+    }
     a.group_order = nullptr;
     a.tile_cost = nullptr;
     a.defer_rec = nullptr;
@@ -1564,6 +1581,13 @@ int vrt_debug_view_in_range(const float inv_view[16]) { return inv_view ? (view_
 
 // A/B switch (tests, tools): 0 makes every launch run the shader's own ray-generation prologue, 1 (default) lets views
 // whose projection allows it read the per-column / per-row tables (ray_table())
+// A/B switch (tests, tools): 0 keeps KArgs::root0_only off (rays that leave wide root 0 walk the empty octants' records)
+int vrt_debug_set_root0_only(vrt_ctx *c, int on) {
+    if (!c) return VRT_E_INVALID;
+    c->root0_only_on = on != 0;
+    return VRT_OK;
+}
+
 int vrt_debug_set_ray_tables(vrt_ctx *c, int on) {
     if (!c) return VRT_E_INVALID;
     c->ray_tables_on = on != 0;

@@ -89,6 +89,7 @@ struct KArgs {
     uint32_t root0_node;
     int root0_shift;
     int root0_min[3];         // minimum corner of wide root 0's cube (valid when n_roots > 0)
+    int root0_only;           // 1: every record outside wide root 0's subtree is an absent child -- the world is empty outside that cube
     // Feedback scheduling (SCHED flavours of trace_kernel; vrt_capi.hip owns the buffers). The unit is a GROUP of
     // kGroupTiles consecutive tiles. bit 0: the g-th group of tiles the launch starts is group_order[g] (a permutation
     // of the launch's groups, heaviest first). bit 1: every wave leaves the clock ticks its tile took in

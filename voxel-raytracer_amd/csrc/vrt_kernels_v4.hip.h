@@ -120,7 +120,14 @@ struct TravT {
             node = anode = a.root0_node << 9;
             cs = acs = (uint32_t)(rs - 2);
             last = p;
-            status = in_world_u(a, p) ? (in0 ? kGo : kDone) : kOutside;
+            // KArgs::root0_only: the tree has nothing outside wide root 0 (the dispatcher checked the records above it). A ray
+            // that HAS BEEN inside that cube -- its walk holds a node: acs != 0 -- and is outside it now cannot come back
+            // (the cube is convex) and has only empty space ahead: it misses whatever it still crosses, so the lookup says
+            // "outside" at once instead of walking the records of the empty octants (1.5 such walks per wave of the bench
+            // frame, 125 vector and 153 scalar instructions each). A ray that has not been inside yet takes the walk.
+            const bool gone = a.root0_only != 0 && w.acs != 0u;
+            status = kGo;
+            if (!in0) status = gone ? kOutside : (in_world_u(a, p) ? kDone : kOutside);
             asm volatile("" : "+v"(status));   // a vector register, not a pair of lane masks to merge
             if (status == kDone) {   // in the world, outside wide root 0: walk the records (v3)
                 v3::Walk w3;
