@@ -104,7 +104,7 @@ struct TravT {
     // test, then wide root 0 when the point lies in its cube -- where the descent from the octree root would arrive
     // anyway -- else the record walk of v3 (the other seven octants of the reference's world: a nested, rarely
     // entered block). Inside the block everything is a select, so its lanes meet again after a handful of instructions.
-    static VRT_DEV int find(const KArgs &a, const Ctx &c, I3 p, F3 pf, I3 dpos, F3 dposf, Walk &w, Found &f) {
+    static VRT_DEV int find(const KArgs &a, const Ctx &c, I3 p, F3 pf, I3 dpos, F3 dposf, Walk &w, Found &f, bool forward, uint32_t leaving_m = 85u) {
         const uint32_t d = (uint32_t)((p.x ^ w.last.x) | (p.y ^ w.last.y) | (p.z ^ w.last.z));
         const bool in_node = (d >> w.cs) < 4u;
         const bool in_anchor = (d >> w.acs) < 4u;     // the anchor contains the node: in_node implies in_anchor
@@ -122,10 +122,16 @@ struct TravT {
             last = p;
             // KArgs::root0_only: the tree has nothing outside wide root 0 (the dispatcher checked the records above it). A ray
             // that HAS BEEN inside that cube -- its walk holds a node: acs != 0 -- and is outside it now cannot come back
-            // (the cube is convex) and has only empty space ahead: it misses whatever it still crosses, so the lookup says
-            // "outside" at once instead of walking the records of the empty octants (1.5 such walks per wave of the bench
-            // frame, 125 vector and 153 scalar instructions each). A ray that has not been inside yet takes the walk.
-            const bool gone = a.root0_only != 0 && w.acs != 0u;
+            // and has only empty space ahead: it misses whatever it still crosses, so the lookup says "outside" at once
+            // instead of walking the records of the empty octants (1.5 such walks per wave of the bench frame, 125 vector
+            // and 153 scalar instructions each). "Cannot come back": every step adds t * dir and a push of dir's sign, so
+            // each coordinate moves one way only, PROVIDED t >= 0 -- true unless a component of dir lies in (-1e-8, 0],
+            // whose reciprocal the shader replaces by +1e20 (comp:256-258) while its plane is the cell's near face: such a
+            // ray steps backwards. `forward` (forward_only()) excludes those; they and rays not yet inside take the walk.
+            // And "misses": empty space is no event only for a ray that is IN empty space -- for one inside a solid or glass
+            // (leaving_m, the medium byte its hit test compares with, is not 85) the empty octant is the hit (found by the
+            // parity fuzz: eyes inside the models' bases, rays leaving through the floor of the cube).
+            const bool gone = a.root0_only != 0 && forward && w.acs != 0u && leaving_m == 85u;
             status = kGo;
             if (!in0) status = gone ? kOutside : (in_world_u(a, p) ? kDone : kOutside);
             asm volatile("" : "+v"(status));   // a vector register, not a pair of lane masks to merge
@@ -170,6 +176,11 @@ struct TravT {
         }
         w.node = node; w.cs = cs; w.anode = anode; w.acs = acs; w.last = last;
         return status;
+    }
+
+    // no component of the direction in (-1e-8, 0]: every step of the DDA has t >= 0 (see find())
+    static VRT_DEV bool forward_only(F3 d) {
+        return (d.x > 0.0f || d.x <= -1e-8f) && (d.y > 0.0f || d.y <= -1e-8f) && (d.z > 0.0f || d.z <= -1e-8f);
     }
 
     static VRT_DEV F3 world_planes(const KArgs &a, I3 dpos) {  // comp:143-145, convention C8: the world's bounds
@@ -229,7 +240,7 @@ struct TravT {
     // the ray's own starting medium on the leaving side (comp:318-326).
     template <bool IOF85>
     static VRT_DEV bool march_loop(const KArgs &a, const Ctx &c, F3 &rp, F3 dir, F3 inv, F3 push, I3 dpos, F3 dposf, Walk &w, Found &cur,
-                                   uint32_t iof_byte, int &axis, uint32_t &px, uint32_t &py, I3 &mp) {
+                                   uint32_t iof_byte, int &axis, uint32_t &px, uint32_t &py, I3 &mp, bool forward) {
         Axis ax{false, false};
         F3 pf;
         int i = 0, status = kGo;
@@ -244,7 +255,7 @@ struct TravT {
             // a ray that leaves the world misses (comp:307-310) and find() leaves `cur` alone then: nothing reads its voxel
             // words afterwards, so the previous voxel is updated unconditionally rather than through selects
             px = cur.x; py = cur.y;
-            status = find(a, c, mp, pf, dpos, dposf, w, cur);
+            status = find(a, c, mp, pf, dpos, dposf, w, cur, forward, prev_m);
             asm volatile("" : "+v"(status));
             bool hit = (cur.y & 0xffu) != prev_m;
             if constexpr (!IOF85) hit = hit && status != kOutside;
@@ -303,15 +314,16 @@ struct TravT {
             reset(w);
             // an eye outside the world: find() has noted that point as the walk's reference, and the next point -- still
             // outside, a few units on -- would pass for a point of wide root 0: no current node again
-            if (find(a, c, mp, pf, dpos, dposf, w, cur) == kOutside) { cur.plane = world_planes(a, dpos); reset(w); }
+            if (find(a, c, mp, pf, dpos, dposf, w, cur, false) == kOutside) { cur.plane = world_planes(a, dpos); reset(w); }
         }
         int axis = 2;
         uint32_t px = 0u, py = 85u | (1u << 23);
         bool hit;
         // one loop per instantiation: choosing between the two per wave (all lanes in refraction 1.0 or not) made the full
         // path tracer hold both and spill 16 registers at its five waves per SIMD
-        if constexpr (EYE85) hit = march_loop<true>(a, c, rp, dir, inv, push, dpos, dposf, w, cur, iof_byte, axis, px, py, mp);
-        else hit = march_loop<false>(a, c, rp, dir, inv, push, dpos, dposf, w, cur, iof_byte, axis, px, py, mp);
+        const bool forward = forward_only(dir);
+        if constexpr (EYE85) hit = march_loop<true>(a, c, rp, dir, inv, push, dpos, dposf, w, cur, iof_byte, axis, px, py, mp, forward);
+        else hit = march_loop<false>(a, c, rp, dir, inv, push, dpos, dposf, w, cur, iof_byte, axis, px, py, mp, forward);
         const float n = -comp(sd, axis);
         h.axis = axis; h.n = n;
         h.map = mp; h.point = rp;
@@ -334,7 +346,10 @@ struct TravT {
         w.node = h.r_node; w.cs = (uint32_t)h.r_s; w.anode = h.r_anode; w.acs = (uint32_t)h.r_as; w.last = h.r_last;
         Found v;
         v.x = 0u; v.y = 85u | (1u << 23); v.plane = F3{0.0f, 0.0f, 0.0f};
-        if (find(a, c, mp, pf, dpos, dposf, w, v) == kOutside) { v.plane = world_planes(a, dpos); reset(w); }   // as in march()
+        const bool forward = forward_only(ld);
+        // the first lookup never takes the root0_only shortcut: the walk it resumes is the primary ray's, and "has been inside
+        // wide root 0" must be this ray's own history (an origin 2e-3 outside the cube's face starts outside)
+        if (find(a, c, mp, pf, dpos, dposf, w, v, false) == kOutside) { v.plane = world_planes(a, dpos); reset(w); }   // as in march()
         int lit = 1, i = 0;
         bool go;
         do {
@@ -345,7 +360,7 @@ struct TravT {
             floor_both(rp, pf, mp);
             ++i;
             go = !occluder && i < 64;
-            if (go) go = find(a, c, mp, pf, dpos, dposf, w, v) != kOutside;
+            if (go) go = find(a, c, mp, pf, dpos, dposf, w, v, forward) != kOutside;
         } while (go);
         return lit;
     }
