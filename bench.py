@@ -285,8 +285,8 @@ def main():
     ctx.set_variant(args.variant)
     if args.no_ray_tables:
         ctx.set_ray_tables(False)
-    if os.environ.get("VRT_BENCH_NO_ROOT0_ONLY"):
-        ctx.set_root0_only(False)   # A/B: rays that leave wide root 0 walk the empty octants' records
+    if os.environ.get("VRT_BENCH_NO_ROOT0_ONLY"):   # A/B: 1 = rays that leave wide root 0 walk the empty octants' records; 2 = the shortcut
+        ctx.set_root0_only({"1": 0, "2": 2}.get(os.environ["VRT_BENCH_NO_ROOT0_ONLY"], 0))   # without the tighter root
     ctx.set_tile_scheduling(args.sched_period)
     ctx.upload_octree(tex, dim)
     ctx.set_camera(ip, iv, cp)

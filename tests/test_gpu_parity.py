@@ -1005,7 +1005,7 @@ def test_rays_leaving_the_only_occupied_cube(ctx, V, O, product_scenes):
                 ctx.set_camera(ip, iv, cp)
                 for mode in (0, 1, 2):
                     ref_rgba, ref_id, _ = _oracle_frame(O, tex, dim, (ip, iv, cp), W, H, mode)
-                    for on in (True, False):
+                    for on in (True, 2, False):   # with the tightest valid root 0, with build_wide()'s, without the shortcut
                         ctx.set_root0_only(on)
                         rgba, idd = ctx.dispatch(W, H, mode)
                         _assert_same(rgba, ref_rgba, f"pose {pose} {W}x{H} mode {mode} shortcut {on} rgba8")

@@ -652,7 +652,7 @@ class Context:
 
     def set_root0_only(self, on):
         """A/B: False = rays that leave wide root 0 always walk the records of the octants around it"""
-        self._chk(hip_lib().vrt_debug_set_root0_only(self._h, 1 if on else 0))
+        self._chk(hip_lib().vrt_debug_set_root0_only(self._h, int(on)))   # True/1: on, 2: on without the tighter root, False/0: off
 
     def set_ray_tables(self, on):
         """A/B: False = every launch runs the shader's own ray-generation prologue (no per-projection tables)"""

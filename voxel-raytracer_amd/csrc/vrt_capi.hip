@@ -182,6 +182,7 @@ struct vrt_ctx {
     };
     std::vector<RayTable> ray_tables;
     uint64_t ray_tick = 0;
+    bool tight_root_on = true;                   // vrt_debug_set_root0_only(2 = on without the tighter root)
     bool root0_only_on = true;                   // vrt_debug_set_root0_only(0): never tell the kernels that the world is empty outside wide root 0
     bool ray_tables_on = true;                   // vrt_debug_set_ray_tables(0): always the shader's own prologue (A/B, tests)
     const uint32_t *dbg_group_order = nullptr;  // vrt_debug_set_tile_order: caller-owned buffers instead of the scheduler's
@@ -514,6 +515,7 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     vrt::ViewSet vs;
     std::memset(&vs, 0, sizeof vs);
     a.n_views = n_views;
+    int eyes[vrt::kMaxViews][3];
     for (int i = 0; i < n_views; ++i) {
         vrt::View &w = vs.v[i];
         std::memcpy(w.inv_proj, views ? views[i].inv_projection : c->inv_proj, sizeof w.inv_proj);
@@ -528,6 +530,7 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
             // float -> int as the device converts: NaN -> 0, out of range saturates (and is outside any world)
             eye[k] = g != g ? 0 : (g >= 2147483648.0f ? 2147483647 : (g < -2147483648.0f ? (-2147483647 - 1) : (int)g));
         }
+        for (int k = 0; k < 3; ++k) eyes[i][k] = eye[k];
         vrt::eye_lookup(c->host_records, c->params.world_min, c->params.world_max, eye, w.eye0, w.eye1);
         vrt::FirstFind ff;
         w.first_valid = (c->wide_ok && vrt::first_find(c->wide, c->params.world_min, c->params.world_max, eye, vrt::v3::kAnchorShift, ff)) ? 1 : 0;
@@ -604,6 +607,37 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
             cur = r.w1;
         }
         a.root0_only = (chain && cur == target) ? 1 : 0;
+    }
+    if (a.root0_only && c->tight_root_on) {
+        // The same argument one level down, as often as it holds: when all of a wide node's content sits in ONE of its 64
+        // cells and that cell is subdivided, the child node is as good a "wide root 0" as its parent -- nothing outside it
+        // either -- provided the launch's eyes lie inside it (their first lookups start there). A tighter root means a
+        // shorter descent whenever a lookup restarts at it, and rays that leave it are done sooner. dragon.vox: the octant
+        // [0, 1024)^3 holds everything in its cell [0, 256)^3, whose 64-unit cells the model spreads over: root 0 becomes
+        // [0, 256)^3. Not below the anchor level (a node of side 2^kAnchorShift).
+        uint32_t node = a.root0_node;
+        int shift = a.root0_shift, mn[3] = {a.root0_min[0], a.root0_min[1], a.root0_min[2]};
+        for (;;) {
+            const int cs = shift - 2;
+            if (cs < vrt::v3::kAnchorShift) break;
+            int only = -1, n = 0;
+            for (int cell = 0; cell < 64 && n < 2; ++cell) {
+                const vrt::WideCell &wc = c->wide.cells[(size_t)node * 64 + (size_t)cell];
+                if ((wc.w1 & vrt::kWideInternal) != 0u || (wc.w0 | (wc.w1 & 0x00ffffffu)) != 0u) { ++n; only = cell; }
+            }
+            if (n != 1) break;
+            const vrt::WideCell &wc = c->wide.cells[(size_t)node * 64 + (size_t)only];
+            if ((wc.w1 & vrt::kWideInternal) == 0u) break;
+            const int o[3] = {mn[0] + (((only >> 4) & 3) << cs), mn[1] + (((only >> 2) & 3) << cs), mn[2] + ((only & 3) << cs)};
+            bool inside = true;
+            for (int i = 0; i < n_views; ++i)
+                for (int k = 0; k < 3; ++k) inside = inside && eyes[i][k] >= o[k] && eyes[i][k] < o[k] + (1 << cs);
+            if (!inside) break;
+            node = wc.w0; shift = cs;
+            for (int k = 0; k < 3; ++k) mn[k] = o[k];
+        }
+        a.root0_node = node; a.root0_shift = shift;
+        for (int k = 0; k < 3; ++k) a.root0_min[k] = mn[k];
     }
     a.group_order = nullptr;
     a.tile_cost = nullptr;
@@ -1585,6 +1619,7 @@ int vrt_debug_view_in_range(const float inv_view[16]) { return inv_view ? (view_
 int vrt_debug_set_root0_only(vrt_ctx *c, int on) {
     if (!c) return VRT_E_INVALID;
     c->root0_only_on = on != 0;
+    c->tight_root_on = on == 1;   // 2: the shortcut with wide root 0 as build_wide() found it
     return VRT_OK;
 }
 
