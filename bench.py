@@ -362,31 +362,62 @@ def main():
     # and with the root rotating over the ranks (frame f assembled on rank f % N). A failure of the mappings is reported,
     # never fatal: the RCCL regions above stand on their own.
     peer = {}
+    peer_stuck = False   # a device-side wait of the peer path never returned on some rank: the process ends through os._exit
     if (world > 1 or os.environ.get("VRT_BENCH_PEER_AT_ONE")) and not os.environ.get("VRT_BENCH_NO_PEER"):
         frames_g = json.load(open(os.path.join(ROOT, "tests", "golden", "frames.json")))["frames"]
         gkey = GOLDEN_KEY[args.map] + ("_full" if mode == 2 and args.map == "dragon" else "") + f"/mode{mode}"
         gg = frames_g.get(gkey)
+        def agree(err):
+            """the first error text any rank reports, the same answer on every rank (ranks must leave a region together)"""
+            if world == 1:
+                return err
+            out = [None] * world
+            dist.all_gather_object(out, err)
+            return next((e for e in out if e), None)
+
+        PEER_TIMEOUT_S = 60.0   # a flag hand-shake that never completes must not take the line with it
         for name, rotate in (("peer_store_rank0", False), ("peer_store_rotating_root", True)):
+            if peer_stuck:
+                peer[name] = {"error": "skipped: an earlier peer region left a device-side wait blocked"}
+                continue
             pp = None
             try:
-                pp = shd.PeerFramePipeline(ctx, plan, n_buf=4, rotate=rotate)
-                why = pp.rehearse()
+                pp = shd.PeerFramePipeline(ctx, plan, n_buf=4, rotate=rotate)   # raises on every rank or on none
+            except Exception as ex:  # noqa: BLE001 -- any failure of the IPC path is a report line, not the end of the bench
+                peer[name] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+                continue
+            try:
+                why = pp.rehearse()                                              # the same text on every rank
                 if why:
                     peer[name] = {"error": why}
                     continue
 
                 def tiles(d_rgba, d_id, stream):
                     ctx.dispatch_tiles(W, H, args.tile_rows, rank, world, mode, d_rgba, d_id, stream)
-                for _ in range(args.warmup):
-                    pp.step(tiles)
-                pp.drain()
+
+                def run(n_frames):
+                    err = None
+                    try:
+                        for _ in range(n_frames):
+                            pp.step(tiles)
+                        if not pp.drain(PEER_TIMEOUT_S):
+                            err = f"rank {rank}: frames did not complete within {PEER_TIMEOUT_S} s"
+                    except Exception as ex:  # noqa: BLE001
+                        err = f"rank {rank}: {type(ex).__name__}: {ex}"
+                    return agree(err)
+
+                why = run(args.warmup)
+                if why:
+                    peer[name] = {"error": why[:300]}
+                    continue
                 if world > 1:
                     dist.barrier()
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
-                for _ in range(args.steps):
-                    pp.step(tiles)
-                pp.drain()
+                why = run(args.steps)
+                if why:
+                    peer[name] = {"error": why[:300]}
+                    continue
                 if world > 1:
                     dist.barrier()
                 torch.cuda.synchronize(dev)
@@ -407,14 +438,21 @@ def main():
                 peer[name] = {"value": round(W * H * args.steps / ep / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(ep / args.steps * 1e3, 5),
                               "frames_match_oracle_golden": (all(checked) if checked else None), "roots_checked": len(checked),
                               "slots": pp.n_buf}
-            except Exception as ex:  # noqa: BLE001 -- any failure of the IPC path is a report line, not the end of the bench
+            except Exception as ex:  # noqa: BLE001
                 peer[name] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
             finally:
-                if pp is not None:
+                stuck = [pp.stuck]
+                if world > 1:
+                    stuck = [None] * world
                     try:
-                        pp.close()
+                        dist.all_gather_object(stuck, pp.stuck)
                     except Exception:  # noqa: BLE001
-                        pass
+                        stuck = [True]
+                peer_stuck = peer_stuck or any(stuck)
+                try:
+                    pp.close()
+                except Exception:  # noqa: BLE001
+                    pass
 
     # one GPU, informational: the same K frames rotating through four streams (no per-launch events; the figure the
     # headline would become if overlapped launches were allowed to blur the per-kernel duration the roofline uses)
@@ -561,6 +599,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, tex, dim, (ip, iv, cp))
         print(json.dumps(out), flush=True)
+    if peer_stuck:      # streams that will never drain: no barrier, no teardown that would wait for them
+        sys.stdout.flush()
+        os._exit(0)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -238,26 +238,53 @@ class PeerFramePipeline:
         self.np = np
         self.n_flags = (world + 1) * n_buf          # 64 bytes apart
         self.local = None
-        mine = None
+        self.maps = {}
+        self.stuck = False            # a device-side wait that never came back: the process must not synchronise again
+        self.streams, self.consumer = [], None
+        # Every rank makes the SAME collective calls in the same order whatever fails locally (a rank that raised early
+        # would leave the others inside a collective): failures travel as text and every rank raises after the exchange.
+        mine, err = None, None
         if self.own:
-            self.local = {"rgba": [ctx.device_alloc(W * H * 4) for _ in range(n_buf)],
-                          "id": [ctx.device_alloc(W * H * 8) for _ in range(n_buf)],
-                          "flags": ctx.device_alloc(64 * self.n_flags)}
-            mine = {"rgba": [ctx.ipc_export(p) for p in self.local["rgba"]], "id": [ctx.ipc_export(p) for p in self.local["id"]],
-                    "flags": ctx.ipc_export(self.local["flags"])}
+            try:
+                self.local = {"rgba": [], "id": [], "flags": None}
+                for _ in range(n_buf):
+                    self.local["rgba"].append(ctx.device_alloc(W * H * 4))
+                    self.local["id"].append(ctx.device_alloc(W * H * 8))
+                self.local["flags"] = ctx.device_alloc(64 * self.n_flags)
+                mine = {"rgba": [ctx.ipc_export(p) for p in self.local["rgba"]], "id": [ctx.ipc_export(p) for p in self.local["id"]],
+                        "flags": ctx.ipc_export(self.local["flags"])}
+            except Exception as ex:  # noqa: BLE001
+                err = f"rank {rank}: {type(ex).__name__}: {ex}"
         gathered = [None] * world
         if world > 1:
-            dist.all_gather_object(gathered, mine, group=group)
+            dist.all_gather_object(gathered, (mine, err), group=group)
         else:
-            gathered = [mine]
-        self.maps = {}
-        for root in self.roots:
-            if root == rank:
-                self.maps[root] = self.local
-            else:
-                h = gathered[root]
-                self.maps[root] = {"rgba": [ctx.ipc_open(x) for x in h["rgba"]], "id": [ctx.ipc_open(x) for x in h["id"]],
-                                   "flags": ctx.ipc_open(h["flags"])}
+            gathered = [(mine, err)]
+        err = next((e for _, e in gathered if e), None)
+        if err is None:
+            try:
+                for root in self.roots:
+                    if root == rank:
+                        self.maps[root] = self.local
+                    else:
+                        h = gathered[root][0]
+                        m = {"rgba": [], "id": [], "flags": None}
+                        self.maps[root] = m          # registered first: close() unmaps whatever was opened
+                        for x in h["rgba"]:
+                            m["rgba"].append(ctx.ipc_open(x))
+                        for x in h["id"]:
+                            m["id"].append(ctx.ipc_open(x))
+                        m["flags"] = ctx.ipc_open(h["flags"])
+            except Exception as ex:  # noqa: BLE001
+                err = f"rank {rank}: {type(ex).__name__}: {ex}"
+        errs = [err]
+        if world > 1:
+            errs = [None] * world
+            dist.all_gather_object(errs, err, group=group)
+        err = next((e for e in errs if e), None)
+        if err is not None:
+            self.close()
+            raise RuntimeError("peer frame buffers: " + err)
         self.frame = 0
         self.seen = {root: 0 for root in self.roots}   # frames of each root enqueued so far
         self.streams = [torch.cuda.Stream() for _ in range(n_buf)]
@@ -298,7 +325,50 @@ class PeerFramePipeline:
             dist.all_gather_object(out, bad, group=self.group)
         else:
             out = [bad]
-        return next((b for b in out if b), None)
+        bad = next((b for b in out if b), None)
+        if bad:
+            return bad
+        # Second half: a DEVICE-side wait on a flag in a root's memory (what step() enqueues for slot reuse). Every rank's
+        # stream 0 waits for consumed[root][0] >= 0x7100 of every root, the roots then write that value, and the host polls
+        # the stream with a time limit. A wait that does not come back is first offered the value through this rank's own
+        # mapping; if that does not release it either the pipeline is marked stuck (the caller must not synchronise it).
+        for root in self.roots:
+            self.ctx.stream_wait_flag(self._consumed(root, 0), 0x7100, self.streams[0].cuda_stream)
+        if world > 1:
+            dist.barrier(group=self.group)
+        if self.own:
+            self.ctx.stream_write_flag(self._consumed(rank, 0), 0x7100, self.consumer.cuda_stream)
+        bad = None
+        if not self._poll([self.streams[0]], timeout_s):
+            bad = f"rank {rank}: a stream wait on a root's flag did not return within {timeout_s} s"
+            for root in self.roots:
+                self.ctx.stream_write_flag(self._consumed(root, 0), 0x7100, self.streams[1].cuda_stream)
+            if not self._poll([self.streams[0]], 2.0):
+                self.stuck = True
+                bad += " (and stays blocked)"
+        out = [None] * world
+        if world > 1:
+            dist.all_gather_object(out, bad, group=self.group)
+        else:
+            out = [bad]
+        bad = next((b for b in out if b), None)
+        if not bad and self.own:
+            self.consumer.synchronize()
+            self.ctx.device_write(self.local["flags"], self.np.zeros(16 * self.n_flags, self.np.uint32))
+        if world > 1:
+            dist.barrier(group=self.group)
+        return bad
+
+    @staticmethod
+    def _poll(streams, timeout_s):
+        """True once every stream has drained, False after timeout_s (host-side spinning: nothing here can block)"""
+        import time
+        t0 = time.time()
+        while True:
+            if all(st.query() for st in streams):
+                return True
+            if time.time() - t0 > timeout_s:
+                return False
 
     def step(self, dispatch_tiles):
         """enqueue frame self.frame: dispatch_tiles(d_rgba, d_id, stream) must trace this rank's tiles on that stream"""
@@ -320,11 +390,18 @@ class PeerFramePipeline:
         self.seen[root] = i + 1
         self.frame += 1
 
-    def drain(self):
+    def drain(self, timeout_s=None):
+        """waits for everything enqueued; with a time limit it spins on the streams instead and returns False (and marks the
+        pipeline stuck) when they do not drain -- a flag hand-shake that never completes must not take the process with it"""
+        if timeout_s is not None:
+            ok = self._poll(self.streams + ([self.consumer] if self.consumer is not None else []), timeout_s)
+            self.stuck = self.stuck or not ok
+            return ok
         for st in self.streams:
             st.synchronize()
         if self.consumer is not None:
             self.consumer.synchronize()
+        return True
 
     def last_frame(self):
         """(rgba [H, W, 4] uint8, id [H, W, 2] int32) of the newest frame assembled on THIS rank (None if it roots none)"""
@@ -336,11 +413,14 @@ class PeerFramePipeline:
                 self.ctx.device_read(self.local["id"][k], (H, W, 2), self.np.int32))
 
     def close(self):
+        if self.stuck:     # freeing under a blocked stream would block too: the memory goes with the process
+            self.maps, self.local = {}, None
+            return
         for root, m in self.maps.items():
-            if root != self.plan.rank:
-                for p in m["rgba"] + m["id"] + [m["flags"]]:
+            if root != self.plan.rank and m is not self.local:
+                for p in m["rgba"] + m["id"] + ([m["flags"]] if m["flags"] else []):
                     self.ctx.ipc_close(p)
         if self.local:
-            for p in self.local["rgba"] + self.local["id"] + [self.local["flags"]]:
+            for p in self.local["rgba"] + self.local["id"] + ([self.local["flags"]] if self.local["flags"] else []):
                 self.ctx.device_free(p)
         self.maps, self.local = {}, None
