@@ -64,7 +64,7 @@ VRT_DEV void begin(const KArgs &a, const T::Ctx &c, F3 origin, F3 dir, uint32_t 
     l.cur.x = 0u; l.cur.y = 85u | (1u << 23); l.cur.plane = F3{0.0f, 0.0f, 0.0f};
     T::reset(l.w);
     const I3 dpos = dpos_of(l.dposf);
-    if (T::find(a, c, mp, pf, dpos, l.dposf, l.w, l.cur) == v4::kOutside) l.cur.plane = T::world_planes(a, dpos);
+    if (T::find(a, c, mp, pf, dpos, l.dposf, l.w, l.cur, false) == v4::kOutside) { l.cur.plane = T::world_planes(a, dpos); T::reset(l.w); }
     l.px = 0u; l.py = 85u | (1u << 23);
     l.iof_b = iof_b;
     l.steps = 0; l.axis = 2;
@@ -80,7 +80,7 @@ VRT_DEV int step(const KArgs &a, const T::Ctx &c, Lane &l) {
     const uint32_t cur_m = l.cur.y & 0xffu;
     const uint32_t prev_m = ((l.cur.x >> 24) == 0u || (l.cur.y & (1u << 29)) != 0u) ? l.iof_b : cur_m;
     l.px = l.cur.x; l.py = l.cur.y;
-    const int status = T::find(a, c, mp, pf, dpos_of(l.dposf), l.dposf, l.w, l.cur);
+    const int status = T::find(a, c, mp, pf, dpos_of(l.dposf), l.dposf, l.w, l.cur, false);
     const bool hit = status != v4::kOutside && (l.cur.y & 0xffu) != prev_m;
     ++l.steps;
     if (hit) return kDoneHit;
