@@ -14,6 +14,15 @@ the rate with the frames left sharded in the ranks' HBM is printed beside it (`s
 `python -m torch.distributed.run --nproc-per-node N bench.py ...`, before this process touches the
 GPU) and relays rank 0's line; started under torchrun it is one of the ranks. Rank 0 prints ONE
 JSON line (contract in the repository README / DESIGN.md section "Measurement").
+
+Timing: W warm-up frames, fence, K timed frames, fence. That region runs twice: first as the
+process's first GPU work (reported as `cold_start`), then -- the headline `value` -- behind 512
+untimed frames that bring the GPU out of its idle clocks (`config.preroll_launches`;
+VRT_BENCH_PREROLL=0 makes the first region the headline). `roofline` is the contract's HBM line
+(reference-requested bytes: cache-served, may pass 1); `issue_roofline` is the bound that binds.
+With N > 1 the headline is the faster verified of two ways of delivering every frame to rank 0
+(`config.delivery`: an RCCL gather per frame, or the kernels' own stores through IPC mappings of
+rank 0's frame); both, the rotating-root form and the sharded-resident rate are in the line.
 """
 import argparse
 import json
