@@ -206,6 +206,9 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
     float fc[3] = {0.0f, 0.0f, 0.0f};
     const float *gl = a.global_light;
     const F3 light{a.light_dir[0], a.light_dir[1], a.light_dir[2]};
+    // x / PI in its in-range form where the dispatcher vouches for the lights' range (KArgs::shade_fast, div_pi_inrange())
+    const bool shade_fast = a.shade_fast != 0;
+    const auto over_pi = [&](float x) { return shade_fast ? div_pi_inrange(x) : x / kPI; };
 
     while (sp > 0) {
         RayS r = stack[--sp];
@@ -219,15 +222,21 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
             continue;
         } else if (!hit) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) fc[k] = fc[k] + tc[k] * sky[k] * kSun * r.weight / kPI;
+            for (int k = 0; k < 3; ++k) fc[k] = fc[k] + over_pi(tc[k] * sky[k] * kSun * r.weight);
             continue;
         }
         const F3 hn{h.axis == 0 ? h.n : 0.0f, h.axis == 1 ? h.n : 0.0f, h.axis == 2 ? h.n : 0.0f};
         F3 normal = hn;
         if (!(len3(hn) > 0.0f)) normal = F3{0.0f, 1.0f, 0.0f};
         const F3 hp = h.point;
-        const F3 hpw{hp.x / a.voxel_scale, hp.y / a.voxel_scale, hp.z / a.voxel_scale};
-        r.dim = r.dim + len3(sub3(hpw, r.o)) / a.voxel_scale;
+        // x / 1.0f == x: at the reference's u_voxelScale of 1 the four divisions are skipped (a wave-uniform branch)
+        F3 hpw = hp;
+        if (a.voxel_scale != 1.0f) {
+            hpw = F3{hp.x / a.voxel_scale, hp.y / a.voxel_scale, hp.z / a.voxel_scale};
+            r.dim = r.dim + len3(sub3(hpw, r.o)) / a.voxel_scale;
+        } else {
+            r.dim = r.dim + len3(sub3(hpw, r.o));
+        }
         Decoded hv = decode_leaf(h.h0, h.h1);
         Decoded last = decode_leaf(h.p0, h.p1);
         if (hv.c[3] <= 0.0f) { hv.p[0] = 1.0f; hv.p[1] = 0.0f; hv.p[2] = 0.0f; }
@@ -290,20 +299,22 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
                 continue;
             } else if (emission > 0.0f) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) fc[k] = fc[k] + tc[k] * sc[k] * emission * r.weight / kPI;
+                for (int k = 0; k < 3; ++k) fc[k] = fc[k] + over_pi(tc[k] * sc[k] * emission * r.weight);
                 continue;
             }
             if (r.depth == 0) {
+                // (the dispatcher's LightSetup, which the primary + shadow kernel takes, costs this one 135 instructions per wave:
+                // at its register budget the uniform values are re-materialised inside the shadow loop)
                 const int lit = TRAV::shadow(a, tc_, add3(hp, scale3(normal, 2e-3f)), light, h);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const float direct = gl[k] * (float)lit * ndotl;
-                    fc[k] = fc[k] + direct * sc[k] * tc[k] * r.weight / kPI;
+                    fc[k] = fc[k] + over_pi(direct * sc[k] * tc[k] * r.weight);
                 }
             } else {
                 const float amb = fmax_c(1.0f - det_expf(-r.dim / 512.0f), 0.01f);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) fc[k] = fc[k] + amb * sc[k] * tc[k] * r.weight / kPI;
+                for (int k = 0; k < 3; ++k) fc[k] = fc[k] + over_pi(amb * sc[k] * tc[k] * r.weight);
                 continue;
             }
             for (int i = 0; i < kIndirectSamples && sp < kMaxRays && r.depth <= kBounces; ++i) {
