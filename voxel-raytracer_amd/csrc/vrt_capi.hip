@@ -36,9 +36,9 @@ struct Variant {
     int wpe;           // waves per SIMD the register allocator is held to (1 = unconstrained)
 };
 
-// Variant 0 is what the library ships: the v4 traversal, seven waves per SIMD; the dispatcher takes v3 when the eye is
-// inside a medium and for the full path tracer, v2 when the scene has no wide form, v1 when it has a unit-size internal
-// node. Variants 1, 4 and 20 select those fallbacks explicitly (tests). Everything else is A/B material and is only
+// Variant 0 is what the library ships: the v4 traversal, seven waves per SIMD (five for the full path tracer, which runs
+// v4's general march loop); the dispatcher takes v3 when a primary / primary + shadow launch has its eye inside a medium,
+// v2 when the scene has no wide form, v1 when it has a unit-size internal node. Variants 1, 4 and 20 select those fallbacks explicitly (tests). Everything else is A/B material and is only
 // compiled into the library with `make AB=1` (-DVRT_AB_VARIANTS); vrt_set_variant() refuses what is not there.
 #ifdef VRT_AB_VARIANTS
 #define VRT_AB 1
