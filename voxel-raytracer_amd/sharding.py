@@ -302,13 +302,36 @@ class PeerFramePipeline:
         reason as text when the mappings do not behave, else None."""
         import time
         world, rank = self.plan.world, self.plan.rank
-        for root in self.roots:
-            self.ctx.stream_write_flag(self._arrived(root, rank, 0), 0x7000 + rank, self.streams[0].cuda_stream)
-        self.streams[0].synchronize()
-        if world > 1:
-            dist.barrier(group=self.group)
-        bad = None
-        if self.own:
+
+        def everyone(err):
+            """the first error text of any rank; every rank calls this at the same points whatever happened to it locally"""
+            out = [err]
+            if world > 1:
+                out = [None] * world
+                dist.all_gather_object(out, err, group=self.group)
+            return next((e for e in out if e), None)
+
+        def guarded(fn):
+            try:
+                return fn()
+            except Exception as ex:  # noqa: BLE001 -- an unsupported call on one rank must not leave the others in a collective
+                return f"rank {rank}: {type(ex).__name__}: {ex}"
+
+        def write_arrivals():
+            for root in self.roots:
+                self.ctx.stream_write_flag(self._arrived(root, rank, 0), 0x7000 + rank, self.streams[0].cuda_stream)
+            if not self._poll([self.streams[0]], timeout_s):
+                self.stuck = True
+                return f"rank {rank}: a flag write through the mapping did not complete within {timeout_s} s"
+            return None
+
+        bad = everyone(guarded(write_arrivals))      # also the barrier between the writes and the roots' reads
+        if bad:
+            return bad
+
+        def read_arrivals():
+            if not self.own:
+                return None
             t0 = time.time()
             want = [0x7000 + r for r in range(world)]
             while True:
@@ -316,48 +339,51 @@ class PeerFramePipeline:
                 if got == want:
                     break
                 if time.time() - t0 > timeout_s:
-                    bad = f"rank {rank}: arrival flags {got} != {want} after {timeout_s} s"
-                    break
+                    return f"rank {rank}: arrival flags {got} != {want} after {timeout_s} s"
                 time.sleep(0.01)
             self.ctx.device_write(self.local["flags"], self.np.zeros(16 * self.n_flags, self.np.uint32))
-        out = [None] * world
-        if world > 1:
-            dist.all_gather_object(out, bad, group=self.group)
-        else:
-            out = [bad]
-        bad = next((b for b in out if b), None)
+            return None
+
+        bad = everyone(guarded(read_arrivals))
         if bad:
             return bad
         # Second half: a DEVICE-side wait on a flag in a root's memory (what step() enqueues for slot reuse). Every rank's
         # stream 0 waits for consumed[root][0] >= 0x7100 of every root, the roots then write that value, and the host polls
         # the stream with a time limit. A wait that does not come back is first offered the value through this rank's own
         # mapping; if that does not release it either the pipeline is marked stuck (the caller must not synchronise it).
-        for root in self.roots:
-            self.ctx.stream_wait_flag(self._consumed(root, 0), 0x7100, self.streams[0].cuda_stream)
-        if world > 1:
-            dist.barrier(group=self.group)
-        if self.own:
-            self.ctx.stream_write_flag(self._consumed(rank, 0), 0x7100, self.consumer.cuda_stream)
-        bad = None
-        if not self._poll([self.streams[0]], timeout_s):
-            bad = f"rank {rank}: a stream wait on a root's flag did not return within {timeout_s} s"
+        def enqueue_waits():
+            for root in self.roots:
+                self.ctx.stream_wait_flag(self._consumed(root, 0), 0x7100, self.streams[0].cuda_stream)
+            return None
+
+        bad = everyone(guarded(enqueue_waits))       # every wait is enqueued before any root releases it
+
+        def release_and_poll():
+            if self.own:
+                self.ctx.stream_write_flag(self._consumed(rank, 0), 0x7100, self.consumer.cuda_stream)
+            if self._poll([self.streams[0]], timeout_s):
+                return None
+            why = f"rank {rank}: a stream wait on a root's flag did not return within {timeout_s} s"
             for root in self.roots:
                 self.ctx.stream_write_flag(self._consumed(root, 0), 0x7100, self.streams[1].cuda_stream)
             if not self._poll([self.streams[0]], 2.0):
                 self.stuck = True
-                bad += " (and stays blocked)"
-        out = [None] * world
-        if world > 1:
-            dist.all_gather_object(out, bad, group=self.group)
-        else:
-            out = [bad]
-        bad = next((b for b in out if b), None)
-        if not bad and self.own:
-            self.consumer.synchronize()
-            self.ctx.device_write(self.local["flags"], self.np.zeros(16 * self.n_flags, self.np.uint32))
-        if world > 1:
-            dist.barrier(group=self.group)
-        return bad
+                why += " (and stays blocked)"
+            return why
+
+        bad2 = everyone(guarded(release_and_poll))   # run even after a failed enqueue: waits that did get enqueued must be released
+        bad = bad or bad2
+
+        def reset_flags():
+            if not bad and self.own:
+                if not self._poll([self.consumer], timeout_s):
+                    self.stuck = True
+                    return f"rank {rank}: the consumer stream did not drain"
+                self.ctx.device_write(self.local["flags"], self.np.zeros(16 * self.n_flags, self.np.uint32))
+            return None
+
+        bad3 = everyone(guarded(reset_flags))        # doubles as the closing barrier
+        return bad or bad3
 
     @staticmethod
     def _poll(streams, timeout_s):
