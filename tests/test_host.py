@@ -527,3 +527,34 @@ def test_ray_table_is_the_shader_formula_per_column_and_row(V):
     assert not V.view_in_range(bad)
     bad = np.array(iv, f).copy(); bad[0:3] = bad[4:7]      # singular
     assert not V.view_in_range(bad)
+
+
+def test_dispatcher_knows_when_the_world_is_empty_outside_wide_root_0(V, product_scenes):
+    """vrt_debug_root0: the dispatcher's two findings about a tree (KArgs::root0_only and the per-launch choice of wide
+    root 0). The shipped maps sit in the octant [0, 1024)^3 and nothing else exists: root0_only; dragon.vox fills only the
+    cell [0, 256)^3 of it, whose 64-unit cells it spreads over, so that cube becomes root 0 for an eye inside it and the
+    octant stays root 0 for an eye outside. A voxel in another octant, or a second occupied 256-cell, ends either finding."""
+    tex, dim = product_scenes["dragon"]
+    only, shift, mn, built = V.root0_choice(tex, (63, 60, 140))
+    assert (only, shift, mn, built) == (True, 8, (0, 0, 0), 10)
+    assert V.root0_choice(tex, (63, 60, 300)) == (True, 10, (0, 0, 0), 10)        # eye outside [0, 256)^3
+    assert V.root0_choice(tex, (-5, 60, 140)) == (True, 10, (0, 0, 0), 10)        # eye in another octant
+    assert V.root0_choice(tex, (63, 60, 5000)) == (True, 10, (0, 0, 0), 10)       # eye outside the world
+    w = V.World()
+    assert w.load_vox(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "maps", "dragon.vox"))
+    w.insert(700, 10, 10, 0x112233ff)                                              # a second occupied cell of the octant
+    t2, _ = w.flatten()
+    assert V.root0_choice(t2, (63, 60, 140)) == (True, 10, (0, 0, 0), 10)
+    w.insert(-3, 10, 10, 0x112233ff)                                               # and one in another octant of the world
+    t3, _ = w.flatten()
+    r = V.root0_choice(t3, (63, 60, 140))
+    assert r is None or r[0] is False
+    # a small model far from the origin of the octant: the chain follows it down to a 64-cube, never below
+    w = V.World()
+    for x in range(600, 604):
+        w.insert(x, 300, 520, 0xa0a0a0ff)
+    t4, _ = w.flatten()
+    only, shift, mn, built = V.root0_choice(t4, (601, 301, 521))
+    assert only and built == 10 and shift == 6 and mn == (576, 256, 512)
+    only, shift, mn, built = V.root0_choice(t4, (601, 301, 700))                   # the eye leaves the 64-cube, not the 256-cube
+    assert only and shift == 8 and mn == (512, 256, 512)

@@ -380,6 +380,23 @@ def ray_table(inv_projection, width, height):
     return (x, y, float(z[0])) if r == 1 else None
 
 
+def root0_choice(texels, eye, world_min=(-1023, -1023, -1023), world_max=(1024, 1024, 1024)):
+    """Host-only (vrt_debug_root0): (root0_only, log2 side of the root chosen for this eye, its minimum corner (3), log2 side
+    of build_wide()'s root), or None when the scene has no wide form."""
+    L = hip_lib()
+    L.vrt_debug_root0.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                  C.POINTER(C.c_int32)]
+    t = np.ascontiguousarray(texels, np.uint8)
+    out = (C.c_int32 * 6)()
+    r = L.vrt_debug_root0(t.ctypes.data if t.size else None, t.size, (C.c_int32 * 3)(*world_min), (C.c_int32 * 3)(*world_max),
+                          (C.c_int32 * 3)(*[int(v) for v in eye]), out)
+    if r == -5:
+        return None
+    if r != 0:
+        raise VrtError(f"vrt_debug_root0 failed ({r})")
+    return bool(out[0]), int(out[1]), (int(out[2]), int(out[3]), int(out[4])), int(out[5])
+
+
 def view_in_range(inv_view):
     L = hip_lib()
     L.vrt_debug_view_in_range.argtypes = [C.c_void_p]

@@ -592,53 +592,14 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     a.root_table = c->d_roots;
     a.root0_node = a.n_roots ? c->wide.roots[0].node : 0u;
     a.root0_shift = a.n_roots ? c->wide.roots[0].shift : 0;
-    a.root0_only = 0;
-    if (a.n_roots == 1u && c->root0_only_on) {
-        // from the octree root down to wide root 0's record every node must have exactly one child, an internal one: then
-        // all else is absent children, i.e. empty space (the shipped maps: the root's only child is the octant [0, 1024)^3)
-        uint32_t cur = 0;
-        const uint32_t target = c->wide.roots[0].record;
-        bool chain = true;
-        for (int depth = 0; chain && cur != target && depth < 16; ++depth) {
-            if (cur >= c->host_records.size()) { chain = false; break; }
-            const vrt::Record &r = c->host_records[cur];
-            const uint32_t mask = r.w0 & 0xffu, leaves = (r.w0 >> 8) & 0xffu;
-            chain = mask != 0u && (mask & (mask - 1u)) == 0u && (leaves & mask) == 0u;
-            cur = r.w1;
-        }
-        a.root0_only = (chain && cur == target) ? 1 : 0;
-    }
-    if (a.root0_only && c->tight_root_on) {
-        // The same argument one level down, as often as it holds: when all of a wide node's content sits in ONE of its 64
-        // cells and that cell is subdivided, the child node is as good a "wide root 0" as its parent -- nothing outside it
-        // either -- provided the launch's eyes lie inside it (their first lookups start there). A tighter root means a
-        // shorter descent whenever a lookup restarts at it, and rays that leave it are done sooner. dragon.vox: the octant
-        // [0, 1024)^3 holds everything in its cell [0, 256)^3, whose 64-unit cells the model spreads over: root 0 becomes
-        // [0, 256)^3. Not below the anchor level (a node of side 2^kAnchorShift).
-        uint32_t node = a.root0_node;
-        int shift = a.root0_shift, mn[3] = {a.root0_min[0], a.root0_min[1], a.root0_min[2]};
-        for (;;) {
-            const int cs = shift - 2;
-            if (cs < vrt::v3::kAnchorShift) break;
-            int only = -1, n = 0;
-            for (int cell = 0; cell < 64 && n < 2; ++cell) {
-                const vrt::WideCell &wc = c->wide.cells[(size_t)node * 64 + (size_t)cell];
-                if ((wc.w1 & vrt::kWideInternal) != 0u || (wc.w0 | (wc.w1 & 0x00ffffffu)) != 0u) { ++n; only = cell; }
-            }
-            if (n != 1) break;
-            const vrt::WideCell &wc = c->wide.cells[(size_t)node * 64 + (size_t)only];
-            if ((wc.w1 & vrt::kWideInternal) == 0u) break;
-            const int o[3] = {mn[0] + (((only >> 4) & 3) << cs), mn[1] + (((only >> 2) & 3) << cs), mn[2] + ((only & 3) << cs)};
-            bool inside = true;
-            for (int i = 0; i < n_views; ++i)
-                for (int k = 0; k < 3; ++k) inside = inside && eyes[i][k] >= o[k] && eyes[i][k] < o[k] + (1 << cs);
-            if (!inside) break;
-            node = wc.w0; shift = cs;
-            for (int k = 0; k < 3; ++k) mn[k] = o[k];
-        }
-        a.root0_node = node; a.root0_shift = shift;
-        for (int k = 0; k < 3; ++k) a.root0_min[k] = mn[k];
-    }
+    // nothing outside wide root 0? (the shipped maps: the octree root's only child is the octant [0, 1024)^3) -- then rays
+    // that leave it are done (find() in vrt_kernels_v4.hip.h), and the same argument one level down, as often as it holds,
+    // lets a deeper node stand in for it: a shorter descent whenever a lookup restarts there, leaving rays done sooner.
+    // dragon.vox: [0, 1024)^3 holds everything in its cell [0, 256)^3, whose 64-unit cells the model spreads over: root 0
+    // becomes [0, 256)^3 for eyes inside it. Not below the anchor level (a node of side 2^kAnchorShift).
+    a.root0_only = (a.n_roots == 1u && c->root0_only_on && vrt::content_only_in_root0(c->host_records, c->wide)) ? 1 : 0;
+    if (a.root0_only && c->tight_root_on)
+        vrt::tighten_root0(c->wide, eyes, n_views, vrt::v3::kAnchorShift, a.root0_node, a.root0_shift, a.root0_min);
     a.group_order = nullptr;
     a.tile_cost = nullptr;
     a.defer_rec = nullptr;
@@ -1615,6 +1576,28 @@ int vrt_debug_view_in_range(const float inv_view[16]) { return inv_view ? (view_
 
 // A/B switch (tests, tools): 0 makes every launch run the shader's own ray-generation prologue, 1 (default) lets views
 // whose projection allows it read the per-column / per-row tables (ray_table())
+// Host-only (tests): what the dispatcher would tell the kernels about wide root 0 for this tree, these world bounds and
+// this eye: out[0] = root0_only, out[1] = log2 of the chosen root's side, out[2..4] = its minimum corner, out[5] = log2 of
+// the side of build_wide()'s root. Returns 0, VRT_E_MALFORMED, or VRT_E_STATE when the scene has no wide form.
+int vrt_debug_root0(const uint8_t *texels, size_t used_bytes, const int32_t wmin[3], const int32_t wmax[3], const int32_t eye[3],
+                    int32_t out[6]) {
+    if (!wmin || !wmax || !eye || !out) return VRT_E_INVALID;
+    vrt::Layout lay;
+    std::string err;
+    if (!vrt::build_layout(texels, used_bytes, lay, err)) return VRT_E_MALFORMED;
+    vrt::WideTree wt;
+    if (vrt::has_unit_internal_node(lay.records, wmin, wmax) || !vrt::build_wide(lay.records, wmin, wmax, wt, err) || wt.roots.empty())
+        return VRT_E_STATE;
+    uint32_t node = wt.roots[0].node;
+    int shift = wt.roots[0].shift, mn[3] = {wt.roots[0].origin[0], wt.roots[0].origin[1], wt.roots[0].origin[2]};
+    out[5] = shift;
+    out[0] = vrt::content_only_in_root0(lay.records, wt) ? 1 : 0;
+    const int eyes[1][3] = {{eye[0], eye[1], eye[2]}};
+    if (out[0]) vrt::tighten_root0(wt, eyes, 1, vrt::v3::kAnchorShift, node, shift, mn);
+    out[1] = shift; out[2] = mn[0]; out[3] = mn[1]; out[4] = mn[2];
+    return VRT_OK;
+}
+
 // A/B switch (tests, tools): 0 keeps KArgs::root0_only off (rays that leave wide root 0 walk the empty octants' records)
 int vrt_debug_set_root0_only(vrt_ctx *c, int on) {
     if (!c) return VRT_E_INVALID;

@@ -211,6 +211,41 @@ bool build_wide(const std::vector<Record> &records, const int wmin[3], const int
     return collect_roots(records, 0, world, 0, out, why);
 }
 
+bool content_only_in_root0(const std::vector<Record> &records, const WideTree &wt) {
+    if (wt.roots.size() != 1) return false;
+    uint32_t cur = 0;
+    const uint32_t target = wt.roots[0].record;
+    for (int depth = 0; cur != target && depth < 16; ++depth) {
+        if (cur >= records.size()) return false;
+        const Record &r = records[cur];
+        const uint32_t mask = r.w0 & 0xffu, leaves = (r.w0 >> 8) & 0xffu;
+        if (mask == 0u || (mask & (mask - 1u)) != 0u || (leaves & mask) != 0u) return false;
+        cur = r.w1;
+    }
+    return cur == target;
+}
+
+void tighten_root0(const WideTree &wt, const int (*eyes)[3], int n, int min_shift, uint32_t &node, int &shift, int origin[3]) {
+    for (;;) {
+        const int cs = shift - 2;
+        if (cs < min_shift || (size_t)node * 64 + 64 > wt.cells.size()) return;
+        int only = -1, count = 0;
+        for (int cell = 0; cell < 64 && count < 2; ++cell) {
+            const WideCell &wc = wt.cells[(size_t)node * 64 + (size_t)cell];
+            if ((wc.w1 & kWideInternal) != 0u || (wc.w0 | (wc.w1 & 0x00ffffffu)) != 0u) { ++count; only = cell; }
+        }
+        if (count != 1) return;
+        const WideCell &wc = wt.cells[(size_t)node * 64 + (size_t)only];
+        if ((wc.w1 & kWideInternal) == 0u) return;
+        const int o[3] = {origin[0] + (((only >> 4) & 3) << cs), origin[1] + (((only >> 2) & 3) << cs), origin[2] + ((only & 3) << cs)};
+        for (int i = 0; i < n; ++i)
+            for (int k = 0; k < 3; ++k)
+                if (eyes[i][k] < o[k] || eyes[i][k] >= o[k] + (1 << cs)) return;
+        node = wc.w0; shift = cs;
+        for (int k = 0; k < 3; ++k) origin[k] = o[k];
+    }
+}
+
 int wide_find_host(const std::vector<Record> &records, const WideTree &wt, const int wmin[3], const int wmax[3],
                    const int p[3], uint32_t &w0, uint32_t &w1, int mn[3], int mx[3]) {
     Box b;

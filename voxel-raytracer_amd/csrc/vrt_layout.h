@@ -91,6 +91,15 @@ inline WideCell to_cell4(WideCell c) {
     return WideCell{c.w0, (b ? b : 85u) | (illum << 8) | ((k & 0x7fu) << 16) | ((t + 1u) << 23) | ((k >> 7) << 28) | (raw0 << 29)};
 }
 
+// True when the tree has nothing outside wide root 0: there is one wide root, and from the octree root down to that root's
+// record every node has exactly one child, an internal one (everything else is absent children, i.e. empty space).
+bool content_only_in_root0(const std::vector<Record> &records, const WideTree &wt);
+
+// With content_only_in_root0(): the deepest wide node that can stand in for wide root 0 in a launch whose eyes are `eyes`
+// (n of them, floor of the camera positions): as long as all of a node's content sits in ONE of its 64 cells, that cell is
+// subdivided, its cube holds every eye and its side stays >= 2^min_shift, the child takes over. in/out: node, shift, origin.
+void tighten_root0(const WideTree &wt, const int (*eyes)[3], int n, int min_shift, uint32_t &node, int &shift, int origin[3]);
+
 // Returns false when the scene cannot be expressed (an internal node of unit size inside an aligned
 // cube, or more than kMaxWideRoots roots): the dispatcher then uses the record-array kernels.
 bool build_wide(const std::vector<Record> &records, const int wmin[3], const int wmax[3], WideTree &out, std::string &why);
