@@ -229,9 +229,13 @@ class PeerFramePipeline:
     The control plane (exchange of the IPC handles) runs over the process group once, at construction.
     """
 
-    def __init__(self, ctx, plan, n_buf=4, rotate=False, group=None):
+    def __init__(self, ctx, plan, n_buf=4, rotate=False, group=None, colour_only=False):
         import numpy as np
         self.ctx, self.plan, self.n_buf, self.rotate, self.group = ctx, plan, n_buf, rotate, group
+        # colour_only: only the rgba8 image (4 of the 12 bytes per pixel) crosses to the root; a rank's (voxelID, dist) rows
+        # stay in its own memory -- where a display pass sharded the same way would read them. A third of the link traffic.
+        self.colour_only = colour_only
+        self.own_id = []
         W, H, world, rank = plan.width, plan.height, plan.world, plan.rank
         self.roots = list(range(world)) if rotate else [0]
         self.own = rank in self.roots
@@ -263,6 +267,9 @@ class PeerFramePipeline:
         err = next((e for _, e in gathered if e), None)
         if err is None:
             try:
+                if colour_only:
+                    for _ in range(n_buf):
+                        self.own_id.append(ctx.device_alloc(W * H * 8))
                 for root in self.roots:
                     if root == rank:
                         self.maps[root] = self.local
@@ -406,7 +413,8 @@ class PeerFramePipeline:
         if i >= self.n_buf:                  # the slot's previous frame must have been consumed
             self.ctx.stream_wait_flag(self._consumed(root, k), i - self.n_buf + 1, stream)
         if self.plan.rows_local:
-            dispatch_tiles(self.maps[root]["rgba"][k], self.maps[root]["id"][k], stream)
+            d_id = self.own_id[k] if (self.colour_only and root != rank) else self.maps[root]["id"][k]
+            dispatch_tiles(self.maps[root]["rgba"][k], d_id, stream)
         self.ctx.stream_write_flag(self._arrived(root, rank, k), i + 1, stream)
         if root == rank:                     # this rank's consumer: frame complete once every rank has arrived
             cs = self.consumer.cuda_stream
@@ -440,7 +448,7 @@ class PeerFramePipeline:
 
     def close(self):
         if self.stuck:     # freeing under a blocked stream would block too: the memory goes with the process
-            self.maps, self.local = {}, None
+            self.maps, self.local, self.own_id = {}, None, []
             return
         for root, m in self.maps.items():
             if root != self.plan.rank and m is not self.local:
@@ -449,4 +457,6 @@ class PeerFramePipeline:
         if self.local:
             for p in self.local["rgba"] + self.local["id"] + ([self.local["flags"]] if self.local["flags"] else []):
                 self.ctx.device_free(p)
-        self.maps, self.local = {}, None
+        for p in self.own_id:
+            self.ctx.device_free(p)
+        self.maps, self.local, self.own_id = {}, None, []
