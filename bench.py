@@ -468,6 +468,77 @@ def main():
                 except Exception:  # noqa: BLE001
                     pass
 
+    # The COMPLETE frame of the reference's loop -- full path tracer, then the display pass -- sharded by row bands with a
+    # 20-row halo, only the displayed image (4 B/pixel) delivered to rank 0 (sharding.ShownFramePipeline). Reported, never
+    # the headline (the metric is primary rays); at one GPU only with --extras.
+    shown = None
+    if (world > 1 or args.extras) and not peer_stuck and not os.environ.get("VRT_BENCH_NO_SHOWN"):
+        sp = None
+        try:
+            sp = shd.ShownFramePipeline(ctx, W, H, rank, world, 2, n_buf=3)
+        except Exception as ex:  # noqa: BLE001
+            shown = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+        if sp is not None:
+            try:
+                def agree2(err):
+                    if world == 1:
+                        return err
+                    out = [None] * world
+                    dist.all_gather_object(out, err)
+                    return next((e for e in out if e), None)
+
+                def run2(n_frames):
+                    err = None
+                    try:
+                        for _ in range(n_frames):
+                            sp.step()
+                        if not sp.drain(60.0):
+                            err = f"rank {rank}: frames did not complete within 60 s"
+                    except Exception as ex:  # noqa: BLE001
+                        err = f"rank {rank}: {type(ex).__name__}: {ex}"
+                    return agree2(err)
+
+                why = run2(max(2, args.warmup))
+                if not why:
+                    if world > 1:
+                        dist.barrier()
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    why = run2(args.steps)
+                    if world > 1:
+                        dist.barrier()
+                    es = time.perf_counter() - t0
+                if why:
+                    shown = {"error": why[:300]}
+                else:
+                    if world > 1:
+                        t = torch.tensor([es], dtype=torch.float64, device="cpu" if via_host else dev)
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                        es = float(t.item())
+                    same = None
+                    if rank == 0:   # against the one-GPU route: whole frame traced, then filtered (tests tie both to the oracle)
+                        ref_rgba, ref_id = ctx.dispatch(W, H, 2)
+                        same = bool((ctx.denoise(ref_rgba, ref_id) == sp.last_shown()).all())
+                    shown = {"frames_per_s": round(args.steps / es, 1), "ms_per_frame": round(es / args.steps * 1e3, 5),
+                             "what": "full path tracer + display pass per frame, row bands with a 20-row halo, the displayed image "
+                                     "(4 B/pixel) delivered to rank 0 through IPC mappings", "rows_traced_per_rank": sp.h1 - sp.h0,
+                             "rows_shown_per_rank": sp.b1 - sp.b0, "same_pixels_as_one_gpu": same}
+            except Exception as ex:  # noqa: BLE001
+                shown = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+            finally:
+                stuck = [sp.stuck]
+                if world > 1:
+                    stuck = [None] * world
+                    try:
+                        dist.all_gather_object(stuck, sp.stuck)
+                    except Exception:  # noqa: BLE001
+                        stuck = [True]
+                peer_stuck = peer_stuck or any(stuck)
+                try:
+                    sp.close()
+                except Exception:  # noqa: BLE001
+                    pass
+
     # one GPU, informational: the same K frames rotating through four streams (no per-launch events; the figure the
     # headline would become if overlapped launches were allowed to blur the per-kernel duration the roofline uses)
     overlapped = None
@@ -607,6 +678,7 @@ def main():
             ("sharded_resident" if gather == "frame" else "every_frame_delivered"): other,
             "rccl_gather_every_frame": rccl_frame,
             "peer_delivery": peer or None,
+            "shown_frame_pipeline": shown,
             "overlapped_frames": overlapped,
             "batched_views": batched,
         }

@@ -176,6 +176,10 @@ int vrt_device_free(vrt_ctx *ctx, void *d_ptr);
 /* synchronous copies between such memory and the host, after the work enqueued on `stream` (NULL: the context's) */
 int vrt_device_read(vrt_ctx *ctx, const void *d_ptr, void *host, size_t bytes, void *stream);
 int vrt_device_write(vrt_ctx *ctx, void *d_ptr, const void *host, size_t bytes, void *stream);
+/* Device-to-device copy ordered on `stream` (NULL: the context's), asynchronous. Either pointer may be a mapping of another
+ * rank's memory (vrt_ipc_open) or another device's (vrt_multi): how a rank hands a finished block of rows -- e.g. its band
+ * of the DISPLAYED image after vrt_denoise -- to the rank that shows it. */
+int vrt_device_copy(vrt_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, void *stream);
 int vrt_ipc_export(vrt_ctx *ctx, void *d_ptr, uint8_t handle[VRT_IPC_HANDLE_BYTES]);
 int vrt_ipc_open(vrt_ctx *ctx, const uint8_t handle[VRT_IPC_HANDLE_BYTES], void **d_ptr);
 int vrt_ipc_close(vrt_ctx *ctx, void *d_ptr);

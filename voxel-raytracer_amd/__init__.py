@@ -158,6 +158,7 @@ def hip_lib():
         L.vrt_device_free.argtypes = [C.c_void_p, C.c_void_p]
         L.vrt_device_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.vrt_device_write.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.vrt_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.vrt_ipc_export.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
         L.vrt_ipc_open.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
         L.vrt_ipc_close.argtypes = [C.c_void_p, C.c_void_p]
@@ -533,6 +534,10 @@ class Context:
     def device_write(self, ptr, arr, stream=None):
         a = np.ascontiguousarray(arr)
         self._chk(self._L.vrt_device_write(self._h, ptr, a.ctypes.data, a.nbytes, stream))
+
+    def device_copy(self, dst, src, nbytes, stream=None):
+        """asynchronous device-to-device copy on `stream`; either side may be an IPC mapping of another rank's memory"""
+        self._chk(self._L.vrt_device_copy(self._h, C.c_void_p(dst), C.c_void_p(src), C.c_size_t(nbytes), C.c_void_p(stream)))
 
     def ipc_export(self, ptr):
         h = C.create_string_buffer(64)

@@ -107,6 +107,15 @@ int vrt_device_write(vrt_ctx *c, void *d_ptr, const void *host, size_t bytes, vo
     return VRT_OK;
 }
 
+int vrt_device_copy(vrt_ctx *c, void *d_dst, const void *d_src, size_t bytes, void *stream) {
+    if (!c || !d_dst || !d_src) return VRT_E_INVALID;
+    if (bytes == 0) return VRT_OK;
+    VRTC_HIP(hipSetDevice(vrt_device(c)));
+    hipStream_t s = stream ? (hipStream_t)stream : (hipStream_t)vrt_stream(c);
+    VRTC_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDefault, s));   // either side may be another device's memory (peer / IPC mapping)
+    return VRT_OK;
+}
+
 static_assert(sizeof(hipIpcMemHandle_t) <= VRT_IPC_HANDLE_BYTES, "the handle travels as 64 opaque bytes");
 
 int vrt_ipc_export(vrt_ctx *c, void *d_ptr, uint8_t handle[VRT_IPC_HANDLE_BYTES]) {

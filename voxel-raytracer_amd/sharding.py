@@ -460,3 +460,131 @@ class PeerFramePipeline:
         for p in self.own_id:
             self.ctx.device_free(p)
         self.maps, self.local, self.own_id = {}, None, []
+
+
+class ShownFramePipeline:
+    """The COMPLETE frame of the reference's loop on N GPUs -- dispatch (src/main.cpp:946, the full path tracer) then the
+    display pass (:951-967, shaders/quad.frag) -- with only the DISPLAYED image crossing to rank 0: 4 bytes per pixel instead
+    of the 12 of the two intermediate images.
+
+    The display pass reads a (2R+1)^2 window, R <= 20, so a rank cannot filter interleaved 8-row tiles; here the frame is cut
+    into N contiguous bands (multiples of 8 rows) and every rank traces its band plus a 20-row halo on either side, filters
+    that sub-image (vrt_denoise: every tap a band pixel needs lies inside it, and where the sub-image ends early the image
+    ends too, so the shader's window clipping is the same), and copies the band's displayed rows into rank 0's frame
+    through an IPC mapping (vrt_device_copy), followed by a stream flag. At N = 8 a 1080p band is 135 rows + 40 of halo:
+    30 % redundant tracing for a third of the traffic and a display pass that scales. Slots, streams and flags as in
+    PeerFramePipeline; rank 0 is the root of every frame."""
+
+    HALO = 20
+
+    def __init__(self, ctx, plan_width, plan_height, rank, world, mode, n_buf=3, group=None, share=None):
+        """share: rank 0's pipeline of the SAME process (tests: all ranks as objects of one process, no IPC, no collective)"""
+        import numpy as np
+        self.np = np
+        self.ctx, self.W, self.H, self.rank, self.world, self.mode, self.n_buf, self.group = ctx, plan_width, plan_height, rank, world, mode, n_buf, group
+        W, H = self.W, self.H
+        tiles = (H + 7) // 8
+        t0, t1 = tiles * rank // world, tiles * (rank + 1) // world
+        self.b0, self.b1 = min(H, t0 * 8), min(H, t1 * 8)                   # this rank's band [b0, b1)
+        self.h0, self.h1 = max(0, self.b0 - self.HALO), min(H, self.b1 + self.HALO)
+        rows = self.h1 - self.h0
+        self.stuck = False
+        self.local, self.maps, self.sub = None, None, []
+        self.streams = [torch.cuda.Stream() for _ in range(n_buf)]
+        self.consumer = torch.cuda.Stream() if rank == 0 else None
+        self.n_flags = (world + 1) * n_buf
+        mine, err = None, None
+        try:
+            if self.b1 > self.b0:
+                for _ in range(n_buf):   # per slot: traced rgba, (voxelID, dist), displayed rgba of the band + halo
+                    self.sub.append((ctx.device_alloc(max(1, rows) * W * 4), ctx.device_alloc(max(1, rows) * W * 8), ctx.device_alloc(max(1, rows) * W * 4)))
+            if rank == 0:
+                self.local = {"shown": [ctx.device_alloc(W * H * 4) for _ in range(n_buf)], "flags": ctx.device_alloc(64 * self.n_flags)}
+                mine = {"shown": [ctx.ipc_export(p) for p in self.local["shown"]], "flags": ctx.ipc_export(self.local["flags"])}
+        except Exception as ex:  # noqa: BLE001
+            err = f"rank {rank}: {type(ex).__name__}: {ex}"
+        in_process = share is not None or (world > 1 and rank == 0 and group == "in-process")
+        gathered = [(mine, err)]
+        if world > 1 and not in_process:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, (mine, err), group=group)
+        err = next((e for _, e in gathered if e), None)
+        if err is None:
+            try:
+                if rank == 0:
+                    self.maps = self.local
+                elif share is not None:
+                    self.maps = share.local          # the same addresses: one process
+                    self.shared = True
+                else:
+                    h = gathered[0][0]
+                    self.maps = {"shown": [], "flags": None}
+                    for x in h["shown"]:
+                        self.maps["shown"].append(ctx.ipc_open(x))
+                    self.maps["flags"] = ctx.ipc_open(h["flags"])
+            except Exception as ex:  # noqa: BLE001
+                err = f"rank {rank}: {type(ex).__name__}: {ex}"
+        errs = [err]
+        if world > 1 and not in_process:
+            errs = [None] * world
+            dist.all_gather_object(errs, err, group=group)
+        err = next((e for e in errs if e), None)
+        if err is not None:
+            self.close()
+            raise RuntimeError("shown-frame buffers: " + err)
+        self.frame = 0
+
+    shared = False
+
+    def _arrived(self, r, k):
+        return self.maps["flags"] + 64 * (r * self.n_buf + k)
+
+    def _consumed(self, k):
+        return self.maps["flags"] + 64 * (self.world * self.n_buf + k)
+
+    def step(self):
+        """enqueue one complete frame: trace band + halo, display pass, hand the band's displayed rows to rank 0"""
+        ctx, W, i = self.ctx, self.W, self.frame
+        k = i % self.n_buf
+        stream = self.streams[k].cuda_stream
+        if i >= self.n_buf:
+            ctx.stream_wait_flag(self._consumed(k), i - self.n_buf + 1, stream)
+        if self.b1 > self.b0:
+            d_rgba, d_id, d_out = self.sub[k]
+            rows = self.h1 - self.h0
+            # full-frame addressing: row y of the frame lands at base + y * W * bytes, so the base is shifted up by h0 rows
+            ctx.dispatch_rows(W, self.H, self.h0, self.h1, self.mode, d_rgba - self.h0 * W * 4, d_id - self.h0 * W * 8, stream)
+            ctx.denoise_device(W, rows, d_rgba, d_id, d_out, stream)
+            ctx.device_copy(self.maps["shown"][k] + self.b0 * W * 4, d_out + (self.b0 - self.h0) * W * 4, (self.b1 - self.b0) * W * 4, stream)
+        ctx.stream_write_flag(self._arrived(self.rank, k), i + 1, stream)
+        if self.rank == 0:
+            cs = self.consumer.cuda_stream
+            for r in range(self.world):
+                ctx.stream_wait_flag(self._arrived(r, k), i + 1, cs)
+            ctx.stream_write_flag(self._consumed(k), i + 1, cs)
+        self.frame += 1
+
+    def drain(self, timeout_s):
+        ok = PeerFramePipeline._poll(self.streams + ([self.consumer] if self.consumer is not None else []), timeout_s)
+        self.stuck = self.stuck or not ok
+        return ok
+
+    def last_shown(self):
+        """rank 0: the newest displayed frame [H, W, 4] uint8"""
+        if self.rank != 0 or self.frame == 0:
+            return None
+        return self.ctx.device_read(self.local["shown"][(self.frame - 1) % self.n_buf], (self.H, self.W, 4), self.np.uint8)
+
+    def close(self):
+        if self.stuck:
+            return
+        if self.maps is not None and self.maps is not self.local and not self.shared:
+            for p in self.maps["shown"] + ([self.maps["flags"]] if self.maps["flags"] else []):
+                self.ctx.ipc_close(p)
+        if self.local:
+            for p in self.local["shown"] + [self.local["flags"]]:
+                self.ctx.device_free(p)
+        for t in self.sub:
+            for p in t:
+                self.ctx.device_free(p)
+        self.maps, self.local, self.sub = None, None, []
