@@ -214,6 +214,12 @@ int vrt_multi_frame_alloc(vrt_multi *m, int width, int height, void **d_rgba8, v
 int vrt_multi_frame_free(vrt_multi *m, void *d_rgba8, void *d_id_dist);
 int vrt_multi_dispatch(vrt_multi *m, int width, int height, int tile_rows, int mode, int delivery, void *d_rgba8,
                        void *d_id_dist);
+/* The frame the reference SHOWS -- dispatch (src/main.cpp:946) then the display pass (:951-967, shaders/quad.frag) -- over the
+ * devices of m: the frame is cut into one band of rows per device (multiples of 8), every device traces its band plus a
+ * 20-row halo on either side (the display pass reads up to 20 rows away), filters that sub-image and copies the band's
+ * displayed rows into d_shown_rgba8 (W*H packed rgba8 on device_ids[0], e.g. from vrt_multi_frame_alloc). Only the displayed
+ * image crosses devices. Returns after enqueueing; the frame is complete once vrt_multi_stream(m)'s work has finished. */
+int vrt_multi_dispatch_frame(vrt_multi *m, int width, int height, int mode, void *d_shown_rgba8);
 int vrt_multi_synchronize(vrt_multi *m);
 void *vrt_multi_stream(vrt_multi *m);                    /* device_ids[0]'s stream: consumers of the frame order themselves after it */
 

@@ -652,6 +652,15 @@ def test_multi_gpu_boundary_rehearsed_on_one_device(V, golden, product_scenes):
                         idd = c0.device_read(d_id, (H, W, 2), np.int32, m.stream())
                         assert "%016x" % V.fnv1a64(rgba) == g["rgba_fnv1a64"], (key, devices, delivery, tile_rows)
                         assert "%016x" % V.fnv1a64(idd) == g["id_dist_fnv1a64"], (key, devices, delivery, tile_rows)
+                if key.endswith("mode2"):
+                    # vrt_multi_dispatch_frame: the DISPLAYED frame (trace + display pass in one row band per device, 20-row
+                    # halos) against the single-context route dispatch -> vrt_denoise, which other tests tie to the oracle
+                    ref_rgba, ref_id = c0.dispatch(W, H, 2)
+                    want = c0.denoise(ref_rgba, ref_id)
+                    for _ in range(3):
+                        m.dispatch_frame(W, H, 2, d_rgba)
+                    shown = c0.device_read(d_rgba, (H, W, 4), np.uint8, m.stream())
+                    _assert_same(shown, want, f"vrt_multi_dispatch_frame over {len(devices)} device entries")
                 m.synchronize()
                 m.frame_free(d_rgba, d_id)
             finally:

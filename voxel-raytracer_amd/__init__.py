@@ -733,6 +733,13 @@ class Multi:
     def dispatch(self, width, height, tile_rows, mode, delivery, d_rgba, d_id):
         self._chk(self._L.vrt_multi_dispatch(self._h, width, height, tile_rows, mode, delivery, d_rgba, d_id))
 
+    def dispatch_frame(self, width, height, mode, d_shown):
+        """vrt_multi_dispatch_frame: the displayed frame (trace + display pass in row bands with a halo) into d_shown on device 0"""
+        self._L.vrt_multi_dispatch_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        r = self._L.vrt_multi_dispatch_frame(self._h, width, height, mode, C.c_void_p(d_shown))
+        if r != 0:
+            raise VrtError(f"vrt_multi_dispatch_frame failed ({r}): {self._L.vrt_multi_last_error(self._h).decode()}")
+
     def synchronize(self):
         self._chk(self._L.vrt_multi_synchronize(self._h))
 

@@ -39,6 +39,8 @@ struct vrt_multi {
     std::vector<hipEvent_t> traced;     // per device: its share of the current frame has been enqueued / finished
     std::vector<void *> shard_rgba, shard_id;   // VRT_DELIVER_GATHER: per-device compact buffers
     std::vector<size_t> shard_pixels;
+    std::vector<void *> band_rgba, band_id, band_shown;   // vrt_multi_dispatch_frame: per-device band + halo (traced, ids, displayed)
+    std::vector<size_t> band_pixels;
     hipEvent_t frame_free = nullptr;    // device 0: the consumers of the previous frame have been enqueued before this point
     std::string err;
 };
@@ -174,6 +176,7 @@ void vrt_destroy_multi(vrt_multi *m) {
         (void)hipSetDevice(m->devices[i]);
         (void)hipStreamSynchronize((hipStream_t)vrt_stream(m->ctx[i]));
         if (i < m->shard_rgba.size()) { (void)hipFree(m->shard_rgba[i]); (void)hipFree(m->shard_id[i]); }
+        if (i < m->band_rgba.size()) { (void)hipFree(m->band_rgba[i]); (void)hipFree(m->band_id[i]); (void)hipFree(m->band_shown[i]); }
         if (i < m->traced.size() && m->traced[i]) (void)hipEventDestroy(m->traced[i]);
     }
     if (m->frame_free) { (void)hipSetDevice(m->devices[0]); (void)hipEventDestroy(m->frame_free); }
@@ -347,6 +350,57 @@ int vrt_multi_dispatch(vrt_multi *m, int width, int height, int tile_rows, int m
         // the shard buffers are free again once the pull kernels have run: the next frame's traces wait for that
         // through frame_free, which is recorded on s0 at the start of the next call
     }
+    return VRT_OK;
+}
+
+// The frame the reference SHOWS (dispatch, then the display pass) over the devices of m: row bands with a 20-row halo, each
+// device traces and filters its band, the band's displayed rows are copied into d_shown_rgba8 on device_ids[0].
+int vrt_multi_dispatch_frame(vrt_multi *m, int width, int height, int mode, void *d_shown_rgba8) {
+    if (!m || !d_shown_rgba8) return m ? mfail(m, VRT_E_INVALID, "vrt_multi_dispatch_frame: null frame") : VRT_E_INVALID;
+    if (width < 1 || height < 1) return mfail(m, VRT_E_INVALID, "vrt_multi_dispatch_frame: bad frame shape");
+    constexpr int kHalo = 20;   // quad.frag's largest radius
+    const int n = (int)m->ctx.size();
+    if (m->band_pixels.size() != (size_t)n) {
+        m->band_rgba.assign((size_t)n, nullptr); m->band_id.assign((size_t)n, nullptr); m->band_shown.assign((size_t)n, nullptr);
+        m->band_pixels.assign((size_t)n, 0);
+    }
+    hipStream_t s0 = (hipStream_t)vrt_stream(m->ctx[0]);
+    VRTM_HIP(m, hipSetDevice(m->devices[0]));
+    VRTM_HIP(m, hipEventRecord(m->frame_free, s0));
+    const int tiles = (height + 7) / 8;
+    for (int i = 0; i < n; ++i) {
+        vrt_ctx *c = m->ctx[(size_t)i];
+        hipStream_t s = (hipStream_t)vrt_stream(c);
+        VRTM_HIP(m, hipSetDevice(m->devices[(size_t)i]));
+        if (i > 0) VRTM_HIP(m, hipStreamWaitEvent(s, m->frame_free, 0));
+        int b0 = tiles * i / n * 8, b1 = tiles * (i + 1) / n * 8;
+        if (b0 > height) b0 = height;
+        if (b1 > height) b1 = height;
+        if (b1 > b0) {
+            const int h0 = b0 - kHalo > 0 ? b0 - kHalo : 0, h1 = b1 + kHalo < height ? b1 + kHalo : height;
+            const size_t px = (size_t)(h1 - h0) * (size_t)width;
+            if (px > m->band_pixels[(size_t)i]) {
+                VRTM_HIP(m, hipStreamSynchronize(s));
+                (void)hipFree(m->band_rgba[(size_t)i]); (void)hipFree(m->band_id[(size_t)i]); (void)hipFree(m->band_shown[(size_t)i]);
+                m->band_rgba[(size_t)i] = m->band_id[(size_t)i] = m->band_shown[(size_t)i] = nullptr;
+                m->band_pixels[(size_t)i] = 0;
+                VRTM_HIP(m, hipMalloc(&m->band_rgba[(size_t)i], px * 4));
+                VRTM_HIP(m, hipMalloc(&m->band_id[(size_t)i], px * 8));
+                VRTM_HIP(m, hipMalloc(&m->band_shown[(size_t)i], px * 4));
+                m->band_pixels[(size_t)i] = px;
+            }
+            // vrt_dispatch_rows addresses its images by frame row: the base is shifted up by h0 rows
+            char *rg = (char *)m->band_rgba[(size_t)i], *id = (char *)m->band_id[(size_t)i], *sh = (char *)m->band_shown[(size_t)i];
+            int r = vrt_dispatch_rows(c, width, height, h0, h1, mode, rg - (size_t)h0 * (size_t)width * 4, id - (size_t)h0 * (size_t)width * 8, nullptr);
+            if (!r) r = vrt_denoise(c, width, h1 - h0, rg, id, sh, nullptr);
+            if (r) return mfail(m, r, std::string("device ") + std::to_string(m->devices[(size_t)i]) + ": " + vrt_last_error(c));
+            VRTM_HIP(m, hipMemcpyAsync((char *)d_shown_rgba8 + (size_t)b0 * (size_t)width * 4, sh + (size_t)(b0 - h0) * (size_t)width * 4,
+                                       (size_t)(b1 - b0) * (size_t)width * 4, hipMemcpyDefault, s));
+        }
+        VRTM_HIP(m, hipEventRecord(m->traced[(size_t)i], s));
+    }
+    VRTM_HIP(m, hipSetDevice(m->devices[0]));
+    for (int i = 1; i < n; ++i) VRTM_HIP(m, hipStreamWaitEvent(s0, m->traced[(size_t)i], 0));
     return VRT_OK;
 }
 
