@@ -70,6 +70,19 @@ int main(int argc, char **argv) {
            "\"rgba_fnv1a64\": \"%016llx\", \"id_dist_fnv1a64\": \"%016llx\"}\n",
            devices.size(), delivery == VRT_DELIVER_GATHER ? "gather" : "peer_store", W, H, s / frames * 1e3, (double)W * H * frames / s / 1e6,
            (unsigned long long)fnv1a64(rgba.data(), rgba.size()), (unsigned long long)fnv1a64(idd.data(), idd.size() * 4));
+    // and the frame the reference puts on screen: full path tracer + display pass, one band of rows per device (20-row
+    // halos), only the displayed image crossing to device 0 -- into the rgba image's storage
+    for (int i = 0; i < 5; ++i) vrt_multi_dispatch_frame(m, W, H, VRT_MODE_FULL, d_rgba);
+    vrt_multi_synchronize(m);
+    const auto t1 = std::chrono::steady_clock::now();
+    const int shown_frames = 50;
+    for (int i = 0; i < shown_frames; ++i)
+        if (vrt_multi_dispatch_frame(m, W, H, VRT_MODE_FULL, d_rgba) != VRT_OK) { fprintf(stderr, "%s\n", vrt_multi_last_error(m)); return 1; }
+    vrt_multi_synchronize(m);
+    const double s2 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+    vrt_device_read(vrt_multi_context(m, 0), d_rgba, rgba.data(), rgba.size(), nullptr);
+    printf("{\"devices\": %zu, \"displayed_frame\": \"full shader + display pass in row bands\", \"ms_per_frame\": %.5f, "
+           "\"shown_fnv1a64\": \"%016llx\"}\n", devices.size(), s2 / shown_frames * 1e3, (unsigned long long)fnv1a64(rgba.data(), rgba.size()));
     vrt_multi_frame_free(m, d_rgba, d_id);
     vrt_destroy_multi(m);
     octree_delete(chunk0);
