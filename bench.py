@@ -515,14 +515,20 @@ def main():
                         t = torch.tensor([es], dtype=torch.float64, device="cpu" if via_host else dev)
                         dist.all_reduce(t, op=dist.ReduceOp.MAX)
                         es = float(t.item())
-                    same = None
-                    if rank == 0:   # against the one-GPU route: whole frame traced, then filtered (tests tie both to the oracle)
+                    same = golden_ok = None
+                    if rank == 0:   # against the one-GPU route (whole frame traced, then filtered) and the oracle's committed hash
+                        got = sp.last_shown()
                         ref_rgba, ref_id = ctx.dispatch(W, H, 2)
-                        same = bool((ctx.denoise(ref_rgba, ref_id) == sp.last_shown()).all())
+                        same = bool((ctx.denoise(ref_rgba, ref_id) == got).all())
+                        gs = json.load(open(os.path.join(ROOT, "tests", "golden", "frames.json")))["frames"].get(
+                            GOLDEN_KEY[args.map] + "_full/mode2", {})
+                        if gs.get("shown_fnv1a64") and (gs.get("width"), gs.get("height")) == (W, H):
+                            golden_ok = "%016x" % V.fnv1a64(got) == gs["shown_fnv1a64"]
                     shown = {"frames_per_s": round(args.steps / es, 1), "ms_per_frame": round(es / args.steps * 1e3, 5),
                              "what": "full path tracer + display pass per frame, row bands with a 20-row halo, the displayed image "
                                      "(4 B/pixel) delivered to rank 0 through IPC mappings", "rows_traced_per_rank": sp.h1 - sp.h0,
-                             "rows_shown_per_rank": sp.b1 - sp.b0, "same_pixels_as_one_gpu": same}
+                             "rows_shown_per_rank": sp.b1 - sp.b0, "same_pixels_as_one_gpu": same,
+                             "matches_oracle_golden": golden_ok}
             except Exception as ex:  # noqa: BLE001
                 shown = {"error": f"{type(ex).__name__}: {ex}"[:300]}
             finally:

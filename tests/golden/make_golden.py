@@ -78,6 +78,8 @@ def main():
                 "root_restarts": st["root_restarts"], "shadow_rays": st["shadow_rays"],
                 "b_algo_bytes": 4 * st["fetches"] + 12 * W * H,
             }
+            if mode == 2 and name.endswith("_full"):  # what the reference puts on screen: quad.frag over the two images
+                frames[f"{name}/mode{mode}"]["shown_fnv1a64"] = "%016x" % O.fnv1a64(O.denoise(rgba, idd))
             if fm is not None:  # per-row fetch totals: exact B_algo of any row shard of the bench frame
                 frames[f"{name}/mode{mode}"]["row_fetches"] = [int(v) for v in fm.sum(axis=1)]
             print(name, mode, frames[f"{name}/mode{mode}"]["rgba_fnv1a64"], st["fetches"] / (W * H))
