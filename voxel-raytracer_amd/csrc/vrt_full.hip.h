@@ -195,12 +195,16 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
     // until it is popped -- no scratch traffic at all for opaque scenes -- was measured: the 17 extra live values push
     // the 96-register build into 20 spills and the frame from 0.261 to 0.282 ms.)
     RayS stack[kMaxRays];
+    // the primary ray starts in registers: pushed and popped at once it made a store -> load round trip through scratch
+    // (17 words each way per lane) before the first step
+    RayS r;
     {
         const float ones[3] = {1.0f, 1.0f, 1.0f};
         const float gl3[3] = {a.global_light[0], a.global_light[1], a.global_light[2]};
-        stack[0] = make_ray(gro, ray_dir, start_iof, 1.0f, gl3, 0.0f, tv.c[3] > 0.0f ? tv.c : ones, tv.c[3] * 5.0f, 0);
+        r = make_ray(gro, ray_dir, start_iof, 1.0f, gl3, 0.0f, tv.c[3] > 0.0f ? tv.c : ones, tv.c[3] * 5.0f, 0);
     }
-    int sp = 1;
+    int sp = 0;
+    bool primary = true;
     const auto push = [&](const RayS &nr) { stack[sp++] = nr; };
     bool deferred = false;
     float fc[3] = {0.0f, 0.0f, 0.0f};
@@ -210,8 +214,9 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
     const bool shade_fast = a.shade_fast != 0;
     const auto over_pi = [&](float x) { return shade_fast ? div_pi_inrange(x) : x / kPI; };
 
-    while (sp > 0) {
-        RayS r = stack[--sp];
+    while (primary || sp > 0) {
+        if (!primary) r = stack[--sp];
+        primary = false;
         Hit h;
         const bool hit = TRAV::march(a, tc_, r.o, r.d, r.iof, iof_to_byte(r.iof), h);
         float tc[3] = {r.tint[0], r.tint[1], r.tint[2]};
