@@ -195,8 +195,8 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
     // until it is popped -- no scratch traffic at all for opaque scenes -- was measured: the 17 extra live values push
     // the 96-register build into 20 spills and the frame from 0.261 to 0.282 ms.)
     RayS stack[kMaxRays];
-    // the primary ray starts in registers: pushed and popped at once it made a store -> load round trip through scratch
-    // (17 words each way per lane) before the first step
+    // the primary ray starts in registers, and so does a diffuse bounce pushed on an empty stack (every bounce of an opaque
+    // scene): pushed and popped at once they made a store -> load round trip through scratch, 17 words each way per lane
     RayS r;
     {
         const float ones[3] = {1.0f, 1.0f, 1.0f};
@@ -204,7 +204,7 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
         r = make_ray(gro, ray_dir, start_iof, 1.0f, gl3, 0.0f, tv.c[3] > 0.0f ? tv.c : ones, tv.c[3] * 5.0f, 0);
     }
     int sp = 0;
-    bool primary = true;
+    bool in_regs = true;   // `r` already holds the ray to march next: the primary ray, or a diffuse bounce pushed on an empty stack
     const auto push = [&](const RayS &nr) { stack[sp++] = nr; };
     bool deferred = false;
     float fc[3] = {0.0f, 0.0f, 0.0f};
@@ -214,9 +214,9 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
     const bool shade_fast = a.shade_fast != 0;
     const auto over_pi = [&](float x) { return shade_fast ? div_pi_inrange(x) : x / kPI; };
 
-    while (primary || sp > 0) {
-        if (!primary) r = stack[--sp];
-        primary = false;
+    while (in_regs || sp > 0) {
+        if (!in_regs) r = stack[--sp];
+        in_regs = false;
         Hit h;
         const bool hit = TRAV::march(a, tc_, r.o, r.d, r.iof, iof_to_byte(r.iof), h);
         float tc[3] = {r.tint[0], r.tint[1], r.tint[2]};
@@ -330,6 +330,9 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
                 if (DEFER && sp == 0) {
                     defer_bounce(a, queue, out_offset, add3(hp, scale3(normal, 1e-1f)), bd, tint, fc, n1, nw, last.c, last.c[3] * 5.0f);
                     deferred = true;
+                } else if (sp == 0) {   // it would be popped at once: it takes r's registers instead of a trip through scratch
+                    r = make_ray(add3(hp, scale3(normal, 1e-1f)), bd, n1, nw, tint, 0.0f, last.c, last.c[3] * 5.0f, r.depth + 1);
+                    in_regs = true;
                 } else {
                     push(make_ray(add3(hp, scale3(normal, 1e-1f)), bd, n1, nw, tint, 0.0f, last.c, last.c[3] * 5.0f, r.depth + 1));
                 }
