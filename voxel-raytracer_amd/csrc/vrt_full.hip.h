@@ -294,7 +294,9 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
                     push(make_ray(add3(hp, scale3(normal, 1e-4f)), reflect3(inc, normal), n1, rw, tc, r.dim, last.c, last.c[3] * 5.0f, r.depth));
             }
             if (refract_i > 0.001f && sp < kMaxRays && !has_tir) {
-                push(make_ray(sub3(hp, scale3(normal, 1e-4f)), refr_dir, n2, r.weight * refract_i, tc, 0.0f, hv.c, hv.c[3] * 5.0f, r.depth));
+                // the last push of this iteration, hence the next ray marched: it takes r's registers (see `in_regs`)
+                r = make_ray(sub3(hp, scale3(normal, 1e-4f)), refr_dir, n2, r.weight * refract_i, tc, 0.0f, hv.c, hv.c[3] * 5.0f, r.depth);
+                in_regs = true;
             }
         } else {  // opaque, comp:573-618
             const float emission = hv.p[1] * 10.0f;
