@@ -472,7 +472,8 @@ def main():
     # 20-row halo, only the displayed image (4 B/pixel) delivered to rank 0 (sharding.ShownFramePipeline). Reported, never
     # the headline (the metric is primary rays); at one GPU only with --extras.
     shown = None
-    if (world > 1 or args.extras) and not peer_stuck and not os.environ.get("VRT_BENCH_NO_SHOWN"):
+    peer_failed = any("error" in v for v in peer.values())   # the same IPC mappings and stream flags: do not try them again
+    if (world > 1 or args.extras) and not peer_stuck and not peer_failed and not os.environ.get("VRT_BENCH_NO_SHOWN"):
         sp = None
         try:
             sp = shd.ShownFramePipeline(ctx, W, H, rank, world, 2, n_buf=3)
