@@ -119,6 +119,10 @@ __global__ __launch_bounds__(kTile *kTile) void denoise_kernel(const Args a) {
 constexpr int kTW = 32;                  // tile width; the height TH is a kernel parameter (16 by default)
 constexpr int kSpanX = kTW + 2 * kMaxR;  // 72
 constexpr int kFull = kMaxR;             // DELTA value of the instance that range-tests every tap
+#ifndef VRT_DENOISE_SHARED_MASK
+#define VRT_DENOISE_SHARED_MASK 1
+#endif
+constexpr bool kDenoiseSharedMask = VRT_DENOISE_SHARED_MASK != 0;
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -185,6 +189,8 @@ __device__ __forceinline__ void tap(const f4 rec, const int cid, f2 &rg, f2 &bc,
 // compiler hoists the row's LDS reads ahead of their use. (Cutting the row into register double-buffered chunks
 // pinned by empty asm statements was measured: 4% faster on a frame where every wave has one radius, 10-25% slower
 // on rendered frames, so the rows are left to the scheduler.)
+// SAME (wave-uniform): every lane's summed pixels carry one id, `cid` holds it PX times, and the comparison and its
+// 0/1 mask are made once per tap for all PX pixels (the compiler merges the identical expressions).
 template <int PX, int RM, int DELTA>
 __device__ __forceinline__ void rows_static(const f4 *row, const int (&cid)[PX], const int (&R)[PX], Acc<PX> &acc) {
     constexpr int D = DELTA < RM ? DELTA : RM;
@@ -335,7 +341,21 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
     if (r_hi != 0) {  // some pixel of this wave is summed
         const int rm = r_hi, delta = r_hi - r_lo;
         const f4 *row = s_rec + (threadIdx.y + kMaxR - rm) * kStride<PX> + threadIdx.x;  // window row -rm, lane column base
-        if (delta == 0)
+        // do the summed pixels of every lane share one id? (pixels with id 0 are passed through: their sums are never read)
+        int one = 0;
+        bool lane_same = true;
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+            if (cid[k] == 0) continue;
+            if (one == 0) one = cid[k];
+            lane_same = lane_same && cid[k] == one;
+        }
+        if (kDenoiseSharedMask && delta == 0 && __builtin_amdgcn_ballot_w64(!lane_same) == 0ull) {
+            int same_id[PX];
+#pragma unroll
+            for (int k = 0; k < PX; ++k) same_id[k] = one;
+            rows_dispatch<PX, 0>(row, rm, same_id, R, acc);
+        } else if (delta == 0)
             rows_dispatch<PX, 0>(row, rm, cid, R, acc);
         else if (delta == 1)
             rows_dispatch<PX, 1>(row, rm, cid, R, acc);
