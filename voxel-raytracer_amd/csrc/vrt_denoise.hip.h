@@ -116,13 +116,13 @@ __global__ __launch_bounds__(kTile *kTile) void denoise_kernel(const Args a) {
 // What bounds it: v_pk_fma_f32 issues in ~6 cycles, not 4 (tools/micro/valu_rate.hip), which puts a tap-and-pixel
 // at ~21 cycles of one SIMD; the dense frame runs within 10% of that, rendered frames lose the rest to the spread
 // of per-tile work (sky tiles are free, radius-20 tiles take ~50 us a wave).
+// Also measured and not kept (round 2): one comparison and mask per tap shared by a lane's two pixels in waves whose summed
+// pixels all carry one id. 17% faster where every wave is like that (the dense frame: 0.405 ms against 0.49), 0-1.5% on
+// rendered frames (dragon 1080p 0.341 / 0.281 scheduled against 0.342 / 0.285): at these poses a voxel face is ~13 pixels
+// wide and a wave's 32 x 4 pixels nearly always hold several ids; it doubled the one-radius instances and spilled.
 constexpr int kTW = 32;                  // tile width; the height TH is a kernel parameter (16 by default)
 constexpr int kSpanX = kTW + 2 * kMaxR;  // 72
 constexpr int kFull = kMaxR;             // DELTA value of the instance that range-tests every tap
-#ifndef VRT_DENOISE_SHARED_MASK
-#define VRT_DENOISE_SHARED_MASK 1
-#endif
-constexpr bool kDenoiseSharedMask = VRT_DENOISE_SHARED_MASK != 0;
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -189,8 +189,6 @@ __device__ __forceinline__ void tap(const f4 rec, const int cid, f2 &rg, f2 &bc,
 // compiler hoists the row's LDS reads ahead of their use. (Cutting the row into register double-buffered chunks
 // pinned by empty asm statements was measured: 4% faster on a frame where every wave has one radius, 10-25% slower
 // on rendered frames, so the rows are left to the scheduler.)
-// SAME (wave-uniform): every lane's summed pixels carry one id, `cid` holds it PX times, and the comparison and its
-// 0/1 mask are made once per tap for all PX pixels (the compiler merges the identical expressions).
 template <int PX, int RM, int DELTA>
 __device__ __forceinline__ void rows_static(const f4 *row, const int (&cid)[PX], const int (&R)[PX], Acc<PX> &acc) {
     constexpr int D = DELTA < RM ? DELTA : RM;
@@ -341,21 +339,7 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
     if (r_hi != 0) {  // some pixel of this wave is summed
         const int rm = r_hi, delta = r_hi - r_lo;
         const f4 *row = s_rec + (threadIdx.y + kMaxR - rm) * kStride<PX> + threadIdx.x;  // window row -rm, lane column base
-        // do the summed pixels of every lane share one id? (pixels with id 0 are passed through: their sums are never read)
-        int one = 0;
-        bool lane_same = true;
-#pragma unroll
-        for (int k = 0; k < PX; ++k) {
-            if (cid[k] == 0) continue;
-            if (one == 0) one = cid[k];
-            lane_same = lane_same && cid[k] == one;
-        }
-        if (kDenoiseSharedMask && delta == 0 && __builtin_amdgcn_ballot_w64(!lane_same) == 0ull) {
-            int same_id[PX];
-#pragma unroll
-            for (int k = 0; k < PX; ++k) same_id[k] = one;
-            rows_dispatch<PX, 0>(row, rm, same_id, R, acc);
-        } else if (delta == 0)
+        if (delta == 0)
             rows_dispatch<PX, 0>(row, rm, cid, R, acc);
         else if (delta == 1)
             rows_dispatch<PX, 1>(row, rm, cid, R, acc);
