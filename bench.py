@@ -22,7 +22,8 @@ VRT_BENCH_PREROLL=0 makes the first region the headline). `roofline` is the cont
 (reference-requested bytes: cache-served, may pass 1); `issue_roofline` is the bound that binds.
 With N > 1 the headline is the faster verified of two ways of delivering every frame to rank 0
 (`config.delivery`: an RCCL gather per frame, or the kernels' own stores through IPC mappings of
-rank 0's frame); both, the rotating-root form and the sharded-resident rate are in the line.
+rank 0's frame); both, the rotating-root form and the sharded-resident rate are in the line, and so is
+`whole_frame_per_gpu`: N whole frames per step, one per GPU, kept where they were traced (weak scaling).
 """
 import argparse
 import json
@@ -303,15 +304,20 @@ def main():
     plan = shd.ShardPlan(W, H, args.tile_rows, rank, world)
     n_streams = args.streams or (1 if world == 1 else 4)
 
-    def timed_region(gather_mode, profile, preroll=0):
+    def timed_region(gather_mode, profile, preroll=0, whole=False):
         """[preroll untimed frames,] W warm-up frames, fence, K timed frames, fence; MAX over ranks.
-        Returns (seconds, pipeline, kernel ms samples)."""
-        pipe = shd.FramePipeline(plan, dev, stage_through_host=via_host, gather=gather_mode, streams=n_streams)
+        Returns (seconds, pipeline, kernel ms samples). whole: every rank traces WHOLE frames of its own and keeps them
+        (a one-rank plan per GPU, no exchange at all); the fences and the MAX over ranks stay."""
+        if whole:
+            pipe = shd.FramePipeline(shd.ShardPlan(W, H, args.tile_rows, 0, 1), dev, gather="final", streams=1, collective=False)
+        else:
+            pipe = shd.FramePipeline(plan, dev, stage_through_host=via_host, gather=gather_mode, streams=n_streams)
+        s_rank, s_world = (0, 1) if whole else (rank, world)
 
         def step():
             k, p_rgba, p_id = pipe.slot()
             # on torch-owned streams, so a gather (and the final assembly) orders itself after the trace
-            ctx.dispatch_shard(W, H, args.tile_rows, rank, world, mode, p_rgba, p_id, pipe.stream_handle(k))
+            ctx.dispatch_shard(W, H, args.tile_rows, s_rank, s_world, mode, p_rgba, p_id, pipe.stream_handle(k))
             pipe.submit(k)
 
         def fence():
@@ -365,6 +371,29 @@ def main():
             same = bool(torch.equal(fr, pipe.frame_views()[0]) and torch.equal(fi, pipe.frame_views()[1]))
         other = {"gather": o_mode, "value": round(W * H * args.steps / eo / 1e6, 2), "unit": "Mrays/s",
                  "ms_per_step": round(eo / args.steps * 1e3, 5), "same_pixels": same}
+
+    # several GPUs, the weak-scaling figure beside the strong one: every GPU traces whole frames of its own (N viewers of one
+    # scene: the tree is replicated anyway) and keeps them in its HBM; nothing crosses a link. The one-GPU configuration
+    # (one stream, feedback scheduling, pre-roll) on every rank at once; every rank checks its frame against the golden hashes.
+    replicas = None
+    if world > 1 and not os.environ.get("VRT_BENCH_ONE_REGION"):
+        ctx.set_tile_scheduling(16)
+        er, pipe_r, _ = timed_region("final", False, PREROLL, whole=True)
+        ctx.set_tile_scheduling(args.sched_period)
+        fg = json.load(open(os.path.join(ROOT, "tests", "golden", "frames.json")))["frames"].get(
+            GOLDEN_KEY[args.map] + ("_full" if mode == 2 and args.map == "dragon" else "") + f"/mode{mode}")
+        ok = None
+        if fg is not None and (fg["width"], fg["height"]) == (W, H):
+            fr, fi = pipe_r.frame_views()
+            ok = ("%016x" % V.fnv1a64(fr.cpu().numpy()) == fg["rgba_fnv1a64"] and
+                  "%016x" % V.fnv1a64(fi.cpu().numpy()) == fg["id_dist_fnv1a64"])
+        oks = [None] * world
+        dist.all_gather_object(oks, ok)
+        replicas = {"value": round(world * W * H * args.steps / er / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(er / args.steps * 1e3, 5),
+                    "scaling": "weak", "frames_per_step": world,
+                    "what": "every GPU traces a whole frame per step and keeps it resident (N viewers of one scene); no exchange",
+                    "frames_match_oracle_golden": (all(oks) if all(o is not None for o in oks) else None)}
+        del pipe_r
 
     # several GPUs: the same delivery with NO collective -- every rank's kernels store their tiles straight into the root's
     # frame through an IPC mapping (xGMI peer stores), ordered by stream flags (sharding.PeerFramePipeline): to rank 0,
@@ -684,6 +713,7 @@ def main():
             "cold_start": cold,
             ("sharded_resident" if gather == "frame" else "every_frame_delivered"): other,
             "rccl_gather_every_frame": rccl_frame,
+            "whole_frame_per_gpu": replicas,
             "peer_delivery": peer or None,
             "shown_frame_pipeline": shown,
             "overlapped_frames": overlapped,
