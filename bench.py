@@ -687,7 +687,9 @@ def main():
         if batched and roofline and batched["launch_avg_ms"]:
             b4 = batched["frames_per_launch"] * roofline["algorithmic_bytes_per_launch"]
             batched["roofline_frac"] = round(b4 / (batched["launch_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        delivery = {"final": "frames stay sharded in HBM, no collective per step; the last frame is gathered to rank 0 and "
+        delivery = {"final": "one rank: every frame is complete where it was traced (rgba8 image, then (voxelID, dist) image, in HBM); "
+                             "nothing to assemble" if world == 1 else
+                             "frames stay sharded in HBM, no collective per step; the last frame is gathered to rank 0 and "
                              "assembled inside the timed region",
                     "frame": "every frame gathered to rank 0 inside the timed region, double-buffered (gather of frame i "
                              "overlaps trace of frame i+1)"}[gather]

@@ -123,6 +123,7 @@ class FramePipeline:
         self.store = plan.frame_store(device) if root else None
         self.index = plan.scatter_index(device) if root else None
         self.pending = [None] * nb    # per slot: None | "resident" | async work handle
+        self.in_place = None          # one rank: the slot whose buffer is the newest complete frame (see _retire)
         self.frame = 0
         # streams > 1: buffer k is traced on HIP stream k, so the drain of one launch (its last, slowest waves) overlaps
         # the ramp-up of the next ones; frames i and i + B share a buffer AND a stream, so they stay ordered. An eighth
@@ -186,6 +187,12 @@ class FramePipeline:
         self.pending[k] = None
         if h == "resident":
             # the frame stays in its shard buffer(s); only the last one is assembled on rank 0, on drain
+            if final and plan.world == 1 and not self.dist:
+                # one rank: its buffer holds every row in frame order -- it IS the frame ([3H, W]: rgba rows, then id/dist
+                # rows), there is nothing to assemble and nothing is copied
+                self._join(k)
+                self.in_place = k
+                return
             if final:
                 self._join(k)
                 gather_frame(plan, self.local[k], self.gathered[0], self.store, self.index, self.group,
@@ -209,6 +216,8 @@ class FramePipeline:
                 self._join(k)
 
     def frame_views(self):
+        if self.in_place is not None:
+            return self.plan.frame_views(self.local[self.in_place].view(3 * self.plan.height, self.plan.width))
         return self.plan.frame_views(self.store)
 
 
