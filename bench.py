@@ -381,7 +381,7 @@ def main():
         er, pipe_r, _ = timed_region("final", False, PREROLL, whole=True)
         ctx.set_tile_scheduling(args.sched_period)
         fg = json.load(open(os.path.join(ROOT, "tests", "golden", "frames.json")))["frames"].get(
-            GOLDEN_KEY[args.map] + ("_full" if mode == 2 and args.map == "dragon" else "") + f"/mode{mode}")
+            GOLDEN_KEY[args.map] + ("_full" if mode == 2 else "") + f"/mode{mode}")
         ok = None
         if fg is not None and (fg["width"], fg["height"]) == (W, H):
             fr, fi = pipe_r.frame_views()
@@ -403,7 +403,7 @@ def main():
     peer_stuck = False   # a device-side wait of the peer path never returned on some rank: the process ends through os._exit
     if (world > 1 or os.environ.get("VRT_BENCH_PEER_AT_ONE")) and not os.environ.get("VRT_BENCH_NO_PEER"):
         frames_g = json.load(open(os.path.join(ROOT, "tests", "golden", "frames.json")))["frames"]
-        gkey = GOLDEN_KEY[args.map] + ("_full" if mode == 2 and args.map == "dragon" else "") + f"/mode{mode}"
+        gkey = GOLDEN_KEY[args.map] + ("_full" if mode == 2 else "") + f"/mode{mode}"
         gg = frames_g.get(gkey)
         def agree(err):
             """the first error text any rank reports, the same answer on every rank (ranks must leave a region together)"""
@@ -625,7 +625,7 @@ def main():
     if rank == 0:
         import numpy as np
         frames = json.load(open(os.path.join(ROOT, "tests", "golden", "frames.json")))["frames"]
-        key = GOLDEN_KEY[args.map] + ("_full" if mode == 2 and args.map == "dragon" else "") + f"/mode{mode}"
+        key = GOLDEN_KEY[args.map] + ("_full" if mode == 2 else "") + f"/mode{mode}"
         g = frames.get(key)
         known = g is not None and (g["width"], g["height"]) == (W, H)
         frame_rgba, frame_id = pipe.frame_views()
@@ -701,7 +701,8 @@ def main():
             "data": (f"tests/golden/maps/{args.map}.vox scene fixture" if args.map != "terrain" else
                      "FastNoiseLite(1337) Perlin height field fixture (tests/golden/terrain.json), reference terrain generator") +
                     ", fixed synthetic camera pose",
-            "config": {"workload": f"{args.map}.vox {W}x{H} {args.mode} rays, pose {pose}", "mode": args.mode,
+            "config": {"workload": (f"{args.map}.vox" if args.map != "terrain" else "terrain height field (BASELINE config 4)") +
+                                   f" {W}x{H} {args.mode} rays, pose {pose}", "mode": args.mode,
                        "sharding": f"interleaved {args.tile_rows}-row tiles over {world} rank(s); " + (
                            "every frame delivered to rank 0 inside the timed region by the ranks' own kernel stores through IPC "
                            "mappings of rank 0's frame buffers (xGMI peer stores, stream flags, four slots)"

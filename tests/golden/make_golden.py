@@ -34,6 +34,10 @@ FRAMES = [
     # BASELINE config 4: the height-field terrain of tests/golden/terrain.json (make_terrain.py), its frozen pose
     ("terrain_1080p", "terrain", 1920, 1080, None, (0, 1)),
     ("terrain_240x136", "terrain", 240, 136, None, (0, 1, 2)),
+    # the full path tracer (+ the displayed frame) at the other configurations' sizes
+    ("monu9_720p_full", "monu9", 1280, 720, (48.5, 60.5, 170.5, -90.0, -12.0), (2,)),
+    ("terrain_1080p_full", "terrain", 1920, 1080, None, (2,)),
+    ("nature_4k_full", "nature", 3840, 2160, (60.5, 80.5, 200.5, -90.0, -20.0), (2,)),
 ]
 
 
@@ -62,8 +66,12 @@ def main():
     if "%016x" % O.fnv1a64(scenes["terrain"][0]) != terr["fnv1a64"]:
         raise SystemExit("terrain: flatten hash differs from terrain.json (run make_terrain.py)")
 
-    frames = {}
+    # `make_golden.py --only name[,name...]`: compute only these entries and merge them into the committed frames.json
+    only = set(sys.argv[sys.argv.index("--only") + 1].split(",")) if "--only" in sys.argv else None
+    frames = json.load(open(os.path.join(HERE, "frames.json")))["frames"] if only else {}
     for name, m, W, H, pose, modes in FRAMES:
+        if only is not None and name not in only:
+            continue
         if pose is None:
             pose = tuple(terr["pose"])
         tex, dim = scenes[m]
