@@ -22,9 +22,9 @@ SURVEY_HASHES = {"dragon": "2de7c1f93b4b006c", "monu9": "dcbfa0413ceb4e8f", "nat
 # (name, map, W, H, pose(x,y,z,yaw,pitch), modes)
 FRAMES = [
     ("dragon_1080p", "dragon", 1920, 1080, (63.5, 60.5, 140.5, -90.0, -10.0), (0, 1)),
-    ("dragon_default_720p", "dragon", 1280, 720, (34.0, 60.0, 34.0, -90.0, 0.0), (0,)),
+    ("dragon_default_720p", "dragon", 1280, 720, (34.0, 60.0, 34.0, -90.0, 0.0), (0, 1, 2)),
     ("monu9_720p", "monu9", 1280, 720, (48.5, 60.5, 170.5, -90.0, -12.0), (0, 1)),
-    ("nature_4k", "nature", 3840, 2160, (60.5, 80.5, 200.5, -90.0, -20.0), (1,)),
+    ("nature_4k", "nature", 3840, 2160, (60.5, 80.5, 200.5, -90.0, -20.0), (0, 1)),
     ("dragon_256x144", "dragon", 256, 144, (63.5, 60.5, 140.5, -90.0, -10.0), (0, 1, 2)),
     ("monu9_192x108", "monu9", 192, 108, (48.5, 60.5, 170.5, -90.0, -12.0), (0, 1, 2)),
     ("nature_200x112", "nature", 200, 112, (60.5, 80.5, 200.5, -90.0, -20.0), (0, 1, 2)),

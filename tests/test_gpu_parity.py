@@ -123,7 +123,8 @@ def test_small_frames_vs_oracle_and_golden(ctx, V, O, golden, product_scenes, ke
 @pytest.mark.parametrize("key", ["dragon_1080p/mode0", "dragon_1080p/mode1", "monu9_720p/mode0", "monu9_720p/mode1",
                                  "dragon_default_720p/mode0", "nature_4k/mode1", "dragon_720p_full/mode2",
                                  "dragon_1080p_full/mode2", "terrain_1080p/mode0", "terrain_1080p/mode1",
-                                 "monu9_720p_full/mode2", "terrain_1080p_full/mode2", "nature_4k_full/mode2"])
+                                 "monu9_720p_full/mode2", "terrain_1080p_full/mode2", "nature_4k_full/mode2",
+                                 "dragon_default_720p/mode1", "dragon_default_720p/mode2", "nature_4k/mode0"])
 def test_full_size_frames_match_committed_hashes(ctx, V, golden, product_scenes, key):
     """BASELINE.json sizes: the oracle's frame hashes were committed by tests/golden/make_golden.py."""
     g = golden["frames"]["frames"][key]
