@@ -36,7 +36,7 @@ def V():
 
 @pytest.fixture(scope="session")
 def golden():
-    return {n: json.load(open(os.path.join(GOLDEN, n + ".json"))) for n in ("flatten", "camera", "frames", "terrain")}
+    return {n: json.load(open(os.path.join(GOLDEN, n + ".json"))) for n in ("flatten", "camera", "frames", "terrain", "color")}
 
 
 @pytest.fixture(scope="session")

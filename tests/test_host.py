@@ -70,6 +70,30 @@ def test_camera_block_bits(V, golden):
     assert list(np.array(p.light_dir, np.float32).view(np.uint32)) == golden["camera"]["light_dir"]
 
 
+def test_colour_functions_are_the_references(V, golden):
+    """include/color.h keeps the reference's names (include/color.h:33-46); tests/golden/color.json holds what the
+    reference's own src/color.c returns for 96 inputs (oracle/ref_color_driver.c)."""
+    L = V.host_lib()
+    for name in ("get_color_rgba", "get_color_rgb", "make_color_rgb", "make_color_rgba"):
+        getattr(L, name).restype = C.c_uint32
+    for name in ("get_red_rgb", "get_red_rgba", "get_green_rgb", "get_green_rgba", "get_blue_rgb", "get_blue_rgba", "get_alpha_rgba"):
+        getattr(L, name).restype = C.c_uint8
+    for c in golden["color"]["cases"]:
+        v = c["in"]
+        rgb = v & 0xffffff
+        b = [(v >> 24) & 255, (v >> 16) & 255, (v >> 8) & 255, v & 255]
+        got = {"make_color_rgb": L.make_color_rgb(C.c_uint8(b[0]), C.c_uint8(b[1]), C.c_uint8(b[2])),
+               "make_color_rgba": L.make_color_rgba(C.c_uint8(b[0]), C.c_uint8(b[1]), C.c_uint8(b[2]), C.c_uint8(b[3])),
+               "get_color_rgba": L.get_color_rgba(C.c_uint32(v)), "get_color_rgb": L.get_color_rgb(C.c_uint32(rgb)),
+               "get_red_rgb": L.get_red_rgb(C.c_uint32(rgb)), "get_red_rgba": L.get_red_rgba(C.c_uint32(v)),
+               "get_green_rgb": L.get_green_rgb(C.c_uint32(rgb)), "get_green_rgba": L.get_green_rgba(C.c_uint32(v)),
+               "get_blue_rgb": L.get_blue_rgb(C.c_uint32(rgb)), "get_blue_rgba": L.get_blue_rgba(C.c_uint32(v)),
+               "get_alpha_rgba": L.get_alpha_rgba(C.c_uint32(v))}
+        for k, want in c.items():
+            if k != "in":
+                assert got[k] == want, (hex(v), k, got[k], want)
+
+
 def _oracle_tree_from(O, xyz, rgba):
     L = O.lib()
     t = O.new_tree()

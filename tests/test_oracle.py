@@ -101,6 +101,24 @@ def test_find_agrees_with_dense_grid(O):
     L.o_octree_delete(tree)
 
 
+def test_leaf_texels_carry_the_reference_colour_getters(O, golden):
+    """tests/golden/color.json is the output of the REFERENCE's src/color.c (oracle/ref_color_driver.c, built in place):
+    the oracle's flattener must put get_red/green/blue_rgba into leaf texel 0 and get_alpha_rgba into texel 1
+    (src/octree.cpp:587-596)."""
+    L = O.lib()
+    for c in golden["color"]["cases"]:
+        tree = O.new_tree()
+        L.o_octree_insert(tree, O.VoxelObj(O.IVec3(3, 5, 7), c["in"], O.Voxel(3.0, 0.0, 0.0)))
+        tex, _ = O.flatten(tree)
+        t = np.asarray(tex, np.uint8).reshape(-1, 4)
+        leaves = [i for i in range(len(t) - 1) if t[i, 3] == 255 and t[i + 1, 0] == 255 and t[i + 1, 1] == 0 and t[i + 1, 2] == 0]
+        assert leaves, c
+        i = leaves[-1]          # the voxel's own leaf is the last one the depth-first writer emits on this path
+        assert tuple(int(v) for v in t[i, :3]) == (c["get_red_rgba"], c["get_green_rgba"], c["get_blue_rgba"]), c
+        assert int(t[i + 1, 3]) == c["get_alpha_rgba"], c
+        L.o_octree_delete(tree)
+
+
 def test_det_math_is_sane(O):
     L = O.lib()
     xs = np.linspace(-20, 5, 101)
