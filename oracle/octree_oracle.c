@@ -266,13 +266,16 @@ size_t o_octree_texel_size(o_octree *t) {
     return total;
 }
 
-/* octree.cpp:556-570 */
-static void encode_pointer(size_t idx, int leaf, uint8_t *out) {
-    uint32_t v = (uint32_t)idx;
+/* octree.cpp:556-570; g_wide (extension, o_octree_texture_wide): address bits 23..30 go to the A byte, which the
+ * reference leaves 0 in pointer texels (headers keep their mask there: their list is at header + 1 by construction) */
+static int g_wide = 0;
+static void encode_pointer(size_t idx, int leaf, uint8_t *out, int is_header) {
+    uint32_t v = (uint32_t)idx & 0x7fffffu;
     if (leaf) v |= 0x800000u;
     out[0] = (uint8_t)(v & 0xff);
     out[1] = (uint8_t)((v >> 8) & 0xff);
     out[2] = (uint8_t)((v >> 16) & 0xff);
+    if (g_wide && !is_header) out[3] = (uint8_t)((idx >> 23) & 0xff);
 }
 
 /* octree.cpp:573-655 ; color getters src/color.c:31-59 */
@@ -299,14 +302,14 @@ static void emit(o_octree *n, uint8_t *tex, size_t *next) {
     (*next)++;
     size_t ptrs = *next;
     *next += (size_t)popcount8(m);
-    encode_pointer(ptrs, 0, &tex[header * 4]);
+    encode_pointer(ptrs, 0, &tex[header * 4], 1);
     tex[header * 4 + 3] = m;
     int slot = 0;
     for (int i = 0; i < 8; i++) {
         if (!((m >> i) & 1)) continue;
         size_t child_addr = *next;
         int leaf = (n->children[i]->children == NULL && n->children[i]->has_voxel);
-        encode_pointer(child_addr, leaf, &tex[(ptrs + (size_t)slot) * 4]);
+        encode_pointer(child_addr, leaf, &tex[(ptrs + (size_t)slot) * 4], 0);
         emit(n->children[i], tex, next);
         slot++;
     }
@@ -324,6 +327,16 @@ uint8_t *o_octree_texture(o_octree *t, size_t *arr_size, size_t tex_dim) {
     size_t next = 0;
     emit(t, tex, &next);
     if (next != n) fprintf(stderr, "oracle: flatten size mismatch %zu vs %zu\n", n, next);
+    return tex;
+}
+
+/* EXTENSION (oracle.h): the same emit with wide child addresses; not thread-safe (g_wide) */
+uint8_t *o_octree_texture_wide(o_octree *t, size_t *arr_size) {
+    if (!t || !arr_size) return NULL;
+    if (o_octree_texel_size(t) >= ((size_t)1 << 31)) return NULL;
+    g_wide = 1;
+    uint8_t *tex = o_octree_texture(t, arr_size, 0);
+    g_wide = 0;
     return tex;
 }
 

@@ -57,6 +57,9 @@ uint8_t *o_octree_texture(o_octree *t, size_t *arr_size, size_t tex_dim);
 /* :405 -- returns hit node or NULL */
 o_octree *o_octree_ray_cast(o_octree *root, o_vec3 origin, o_vec3 dir,
                             o_vec3 world_min, o_vec3 world_max);
+/* NON-REFERENCE EXTENSION of :556-570/:657: the same stream with 31-bit child addresses (bits 23..30 in the pointer
+ * texel's A byte); see o_scene.wide_pointers. Identical bytes to o_octree_texture() below 2^23 texels. */
+uint8_t *o_octree_texture_wide(o_octree *t, size_t *arr_size);
 /* tex_dim = ceil(cbrt(texels)), min 1 (src/main.cpp:265-268) */
 uint32_t o_tex_dim_for(size_t texels);
 /* src/main.cpp:487-503 terrain generator over a height field given as data (config 4) */
@@ -101,6 +104,13 @@ typedef struct {
     float light_dir[3];      /* lightDir */
     int32_t highlighted[3];  /* u_highlightedVoxel */
     float inv_proj[16], inv_view[16], cam_pos[4]; /* Camera UBO, column-major */
+    /* NON-REFERENCE EXTENSION (0 = the reference's format, the default): a texel stream written by
+     * o_octree_texture_wide() for trees beyond the 2^23 texels a 23-bit pointer texel (src/octree.cpp:556-570,
+     * comp:89-96) can address. Same texel order and contents; the only differences: a pointer texel's A byte (always
+     * 0 in the reference) carries address bits 23..30, and a header's pointer list is taken to start at the header's
+     * own address + 1 (where the reference's writer always puts it, octree.cpp:606-625) instead of being read from
+     * the header's 23 address bits. For streams below 2^23 texels both readers see the same tree. */
+    int32_t wide_pointers;
 } o_scene;
 
 typedef struct {

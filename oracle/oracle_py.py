@@ -45,7 +45,8 @@ class Scene(C.Structure):
     _fields_ = [("texels", C.c_void_p), ("n_texels", C.c_size_t), ("tex_dim", C.c_int32),
                 ("voxel_scale", C.c_float), ("bounds_min", C.c_int32 * 3), ("bounds_max", C.c_int32 * 3),
                 ("global_light", C.c_float * 4), ("light_dir", C.c_float * 3), ("highlighted", C.c_int32 * 3),
-                ("inv_proj", C.c_float * 16), ("inv_view", C.c_float * 16), ("cam_pos", C.c_float * 4)]
+                ("inv_proj", C.c_float * 16), ("inv_view", C.c_float * 16), ("cam_pos", C.c_float * 4),
+                ("wide_pointers", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -80,6 +81,8 @@ def lib():
         L.o_octree_texel_size.argtypes = [C.POINTER(Octree)]
         L.o_octree_texture.restype = C.POINTER(C.c_uint8)
         L.o_octree_texture.argtypes = [C.POINTER(Octree), C.POINTER(C.c_size_t), C.c_size_t]
+        L.o_octree_texture_wide.restype = C.POINTER(C.c_uint8)
+        L.o_octree_texture_wide.argtypes = [C.POINTER(Octree), C.POINTER(C.c_size_t)]
         L.o_octree_ray_cast.restype = C.POINTER(Octree)
         L.o_octree_ray_cast.argtypes = [C.POINTER(Octree), Vec3, Vec3, Vec3, Vec3]
         L.o_fill_heights.argtypes = [C.POINTER(Octree), C.c_void_p] + [C.c_int] * 8
@@ -116,13 +119,14 @@ def new_tree():
     return lib().o_octree_create(None, IVec3(*WORLD_MIN), IVec3(*WORLD_MAX))
 
 
-def flatten(tree):
-    """-> (uint8 ndarray of texel bytes (may be empty), tex_dim)"""
+def flatten(tree, wide=False):
+    """-> (uint8 ndarray of texel bytes (may be empty), tex_dim). wide: the NON-REFERENCE extension stream of
+    o_octree_texture_wide() (31-bit child addresses) for trees beyond 2^23 texels; render it with make_scene(wide=True)."""
     L = lib()
     n = L.o_octree_texel_size(tree)
     dim = L.o_tex_dim_for(n)
     sz = C.c_size_t(0)
-    p = L.o_octree_texture(tree, C.byref(sz), dim)
+    p = L.o_octree_texture_wide(tree, C.byref(sz)) if wide else L.o_octree_texture(tree, C.byref(sz), dim)
     if not p:
         return np.zeros(0, np.uint8), int(dim)
     arr = np.ctypeslib.as_array(p, shape=(sz.value,)).copy()
@@ -158,7 +162,7 @@ def camera_ubo(pos, yaw, pitch, width, height):
     return (np.array(ip, np.float32), np.array(iv, np.float32), np.array(cp, np.float32)), cam
 
 
-def make_scene(texels, tex_dim, inv_proj, inv_view, cam_pos, highlighted=(-1, -1, -1)):
+def make_scene(texels, tex_dim, inv_proj, inv_view, cam_pos, highlighted=(-1, -1, -1), wide=False):
     L = lib()
     s = Scene()
     L.o_scene_defaults(C.byref(s))
@@ -171,6 +175,7 @@ def make_scene(texels, tex_dim, inv_proj, inv_view, cam_pos, highlighted=(-1, -1
     s.inv_view[:] = [float(x) for x in inv_view]
     s.cam_pos[:] = [float(x) for x in cam_pos]
     s.highlighted[:] = list(highlighted)
+    s.wide_pointers = 1 if wide else 0
     return s
 
 

@@ -234,7 +234,7 @@ static vox_t octree_find(ctx_t *c, i3 wp, i3 *min_b, i3 *max_b, int32_t *cur_coo
             d.props[0] = pr * 3.0f; d.props[1] = pg; d.props[2] = pb; /* comp:126-128 */
             return d;
         }
-        uint32_t base = nd & 0x7fffffu;              /* comp:89-96 */
+        uint32_t base = s->wide_pointers ? (uint32_t)d.coord + 1u : (nd & 0x7fffffu);   /* comp:89-96; EXT: see oracle.h */
         i3 mid = {d.nmin.x + (d.nmax.x - d.nmin.x) / 2, d.nmin.y + (d.nmax.y - d.nmin.y) / 2,
                   d.nmin.z + (d.nmax.z - d.nmin.z) / 2};
         int ci = (wp.x >= mid.x ? 4 : 0) + (wp.y >= mid.y ? 2 : 0) + (wp.z >= mid.z ? 1 : 0);
@@ -242,7 +242,7 @@ static vox_t octree_find(ctx_t *c, i3 wp, i3 *min_b, i3 *max_b, int32_t *cur_coo
         int exists = (mask >> ci) & 1u;
         uint32_t off = (uint32_t)popc8(mask & ((1u << ci) - 1u));
         uint32_t ptr = fetch(c, (int32_t)(base + off));  /* fetched even when absent, comp:196-199 */
-        uint32_t next = ptr & 0x7fffffu;
+        uint32_t next = (ptr & 0x7fffffu) | (s->wide_pointers ? (ptr >> 24) << 23 : 0u);
         is_leaf = (ptr & 0x800000u) != 0;
         *cur_coord = d.coord; *min_b = d.nmin; *max_b = d.nmax;
         c->par_depth = depth;
@@ -626,7 +626,7 @@ int o_find_point(const o_scene *s, const int32_t pos[3], uint8_t leaf[8], int32_
     (void)cur;
     for (int i = 0; i < 16; i++) {
         uint32_t nd = fetch(&c, coord);
-        uint32_t base = nd & 0x7fffffu, mask = nd >> 24;
+        uint32_t base = s->wide_pointers ? (uint32_t)coord + 1u : (nd & 0x7fffffu), mask = nd >> 24;
         i3 mid = {nmin.x + (nmax.x - nmin.x) / 2, nmin.y + (nmax.y - nmin.y) / 2, nmin.z + (nmax.z - nmin.z) / 2};
         int ci = (p.x >= mid.x ? 4 : 0) + (p.y >= mid.y ? 2 : 0) + (p.z >= mid.z ? 1 : 0);
         if (ci & 4) nmin.x = mid.x; else nmax.x = mid.x;
@@ -635,7 +635,7 @@ int o_find_point(const o_scene *s, const int32_t pos[3], uint8_t leaf[8], int32_
         mn[0] = nmin.x; mn[1] = nmin.y; mn[2] = nmin.z; mx[0] = nmax.x; mx[1] = nmax.y; mx[2] = nmax.z;
         if (!((mask >> ci) & 1u)) return 0;
         uint32_t ptr = fetch(&c, (int32_t)(base + (uint32_t)popc8(mask & ((1u << ci) - 1u))));
-        coord = (int32_t)(ptr & 0x7fffffu);
+        coord = (int32_t)((ptr & 0x7fffffu) | (s->wide_pointers ? (ptr >> 24) << 23 : 0u));
         if (ptr & 0x800000u) {
             uint32_t a = fetch(&c, coord), b = fetch(&c, coord + 1);
             memcpy(leaf, &a, 4); memcpy(leaf + 4, &b, 4);

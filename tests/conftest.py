@@ -36,7 +36,7 @@ def V():
 
 @pytest.fixture(scope="session")
 def golden():
-    return {n: json.load(open(os.path.join(GOLDEN, n + ".json"))) for n in ("flatten", "camera", "frames", "terrain", "color")}
+    return {n: json.load(open(os.path.join(GOLDEN, n + ".json"))) for n in ("flatten", "camera", "frames", "terrain", "color", "room")}
 
 
 @pytest.fixture(scope="session")
@@ -49,7 +49,32 @@ def product_scenes(V):
         out[m] = w.flatten()
         w.close()
     out["terrain"] = terrain_world(V).flatten()
+    out["room"] = room_world(V).flatten()
     return out
+
+
+def room_world(V):
+    """The reference's translucent room (src/main.cpp:505-633 as the ordered insert list tests/golden/room.npz, written by
+    make_room.py) built by the PRODUCT host library"""
+    d = np.load(os.path.join(GOLDEN, "room.npz"))
+    mats = json.load(open(os.path.join(GOLDEN, "room.json")))["materials"]
+    w = V.World()
+    for (x, y, z), c, m in zip(d["xyz"], d["color"], d["material"]):
+        mm = mats[int(m)]
+        w.insert(int(x), int(y), int(z), int(c), mm["refraction"], mm["illumination"], mm["k"])
+    return w
+
+
+def room_tree(O):
+    """the same insert list into an ORACLE tree"""
+    d = np.load(os.path.join(GOLDEN, "room.npz"))
+    mats = json.load(open(os.path.join(GOLDEN, "room.json")))["materials"]
+    t = O.new_tree()
+    L = O.lib()
+    for (x, y, z), c, m in zip(d["xyz"], d["color"], d["material"]):
+        mm = mats[int(m)]
+        L.o_octree_insert(t, O.VoxelObj(O.IVec3(int(x), int(y), int(z)), int(c), O.Voxel(mm["refraction"], mm["illumination"], mm["k"])))
+    return t
 
 
 def terrain_world(V, window=None):

@@ -38,7 +38,40 @@ FRAMES = [
     ("monu9_720p_full", "monu9", 1280, 720, (48.5, 60.5, 170.5, -90.0, -12.0), (2,)),
     ("terrain_1080p_full", "terrain", 1920, 1080, None, (2,)),
     ("nature_4k_full", "nature", 3840, 2160, (60.5, 80.5, 200.5, -90.0, -20.0), (2,)),
+    # BASELINE config 4 at its named extent: the whole 1024 x 1024 height field, 24.07 M texels -- beyond the 2^23 a
+    # reference pointer texel addresses, so the oracle reads it through its wide-pointer stream (a NON-REFERENCE extension,
+    # oracle.h o_scene.wide_pointers) and the product takes it as records (vrth_world_records -> vrt_upload_records)
+    ("terrain_full_1080p", "terrain_full", 1920, 1080, None, (0, 1)),
+    ("terrain_full_1080p_full", "terrain_full", 1920, 1080, None, (2,)),
+    ("terrain_full_240x136", "terrain_full", 240, 136, None, (0, 1, 2)),
+    # the reference's own translucent scene (src/main.cpp:505-633 as data: make_room.py), from inside and outside the room
+    ("room_inside_1080p", "room", 1920, 1080, "inside", (0, 1)),
+    ("room_inside_1080p_full", "room", 1920, 1080, "inside", (2,)),
+    ("room_inside_720p_full", "room", 1280, 720, "inside", (2,)),
+    ("room_outside_1080p_full", "room", 1920, 1080, "outside", (2,)),
+    ("room_outside_720p_full", "room", 1280, 720, "outside", (2,)),
+    ("room_inside_256x144", "room", 256, 144, "inside", (0, 1, 2)),
+    ("room_outside_256x144", "room", 256, 144, "outside", (0, 1, 2)),
 ]
+
+
+def room_tree():
+    """the ordered octree_insert calls of tests/golden/room.npz into an oracle tree"""
+    import numpy as np
+    d = np.load(os.path.join(HERE, "room.npz"))
+    mats = json.load(open(os.path.join(HERE, "room.json")))["materials"]
+    t = O.new_tree()
+    L = O.lib()
+    for (x, y, z), c, m in zip(d["xyz"], d["color"], d["material"]):
+        mm = mats[int(m)]
+        L.o_octree_insert(t, O.VoxelObj(O.IVec3(int(x), int(y), int(z)), int(c), O.Voxel(mm["refraction"], mm["illumination"], mm["k"])))
+    return t
+
+
+def only_has(prefix):
+    if "--only" not in sys.argv:
+        return True
+    return any(n.startswith(prefix) for n in sys.argv[sys.argv.index("--only") + 1].split(","))
 
 
 def main():
@@ -66,6 +99,16 @@ def main():
     if "%016x" % O.fnv1a64(scenes["terrain"][0]) != terr["fnv1a64"]:
         raise SystemExit("terrain: flatten hash differs from terrain.json (run make_terrain.py)")
 
+    wide = set()
+    if only_has("terrain_full"):
+        t = O.new_tree()
+        O.fill_heights(t, np.load(os.path.join(HERE, "terrain_heights.npz"))["heights"], 0, 0, 1024, 1024, terr["band"], terr["floor"])
+        scenes["terrain_full"] = O.flatten(t, wide=True)
+        wide.add("terrain_full")
+        O.lib().o_octree_delete(t)
+    room = json.load(open(os.path.join(HERE, "room.json")))
+    scenes["room"] = O.flatten(room_tree())
+
     # `make_golden.py --only name[,name...]`: compute only these entries and merge them into the committed frames.json
     only = set(sys.argv[sys.argv.index("--only") + 1].split(",")) if "--only" in sys.argv else None
     frames = json.load(open(os.path.join(HERE, "frames.json")))["frames"] if only else {}
@@ -74,9 +117,11 @@ def main():
             continue
         if pose is None:
             pose = tuple(terr["pose"])
+        elif isinstance(pose, str):
+            pose = tuple(room["poses"][pose])
         tex, dim = scenes[m]
         (ip, iv, cp), _ = O.camera_ubo(pose[:3], pose[3], pose[4], W, H)
-        s = O.make_scene(tex, dim, ip, iv, cp)
+        s = O.make_scene(tex, dim, ip, iv, cp, wide=m in wide)
         for mode in modes:
             rgba, idd, fm, st = O.render(s, W, H, mode, want_fetch_map=name.endswith('1080p') or name.endswith('1080p_full'))
             frames[f"{name}/mode{mode}"] = {
@@ -86,6 +131,8 @@ def main():
                 "root_restarts": st["root_restarts"], "shadow_rays": st["shadow_rays"],
                 "b_algo_bytes": 4 * st["fetches"] + 12 * W * H,
             }
+            if m in wide:
+                frames[f"{name}/mode{mode}"]["oracle_stream"] = "wide-pointer extension (non-reference): %d texels" % (tex.size // 4)
             if mode == 2 and name.endswith("_full"):  # what the reference puts on screen: quad.frag over the two images
                 frames[f"{name}/mode{mode}"]["shown_fnv1a64"] = "%016x" % O.fnv1a64(O.denoise(rgba, idd))
             if fm is not None:  # per-row fetch totals: exact B_algo of any row shard of the bench frame

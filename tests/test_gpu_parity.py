@@ -103,7 +103,9 @@ def test_full_mode_math_conventions_match_oracle(ctx, O):
 @pytest.mark.parametrize("key", ["dragon_256x144/mode0", "dragon_256x144/mode1", "monu9_192x108/mode0",
                                  "monu9_192x108/mode1", "nature_200x112/mode0", "nature_200x112/mode1",
                                  "dragon_inside_101x67/mode0", "dragon_inside_101x67/mode1", "dragon_256x144/mode2",
-                                 "monu9_192x108/mode2", "nature_200x112/mode2", "dragon_inside_101x67/mode2"])
+                                 "monu9_192x108/mode2", "nature_200x112/mode2", "dragon_inside_101x67/mode2",
+                                 "room_inside_256x144/mode0", "room_inside_256x144/mode1", "room_inside_256x144/mode2",
+                                 "room_outside_256x144/mode0", "room_outside_256x144/mode1", "room_outside_256x144/mode2"])
 def test_small_frames_vs_oracle_and_golden(ctx, V, O, golden, product_scenes, key):
     g = golden["frames"]["frames"][key]
     tex, dim = product_scenes[g["map"]]
@@ -124,7 +126,9 @@ def test_small_frames_vs_oracle_and_golden(ctx, V, O, golden, product_scenes, ke
                                  "dragon_default_720p/mode0", "nature_4k/mode1", "dragon_720p_full/mode2",
                                  "dragon_1080p_full/mode2", "terrain_1080p/mode0", "terrain_1080p/mode1",
                                  "monu9_720p_full/mode2", "terrain_1080p_full/mode2", "nature_4k_full/mode2",
-                                 "dragon_default_720p/mode1", "dragon_default_720p/mode2", "nature_4k/mode0"])
+                                 "dragon_default_720p/mode1", "dragon_default_720p/mode2", "nature_4k/mode0",
+                                 "room_inside_1080p/mode0", "room_inside_1080p/mode1", "room_inside_1080p_full/mode2",
+                                 "room_inside_720p_full/mode2", "room_outside_1080p_full/mode2", "room_outside_720p_full/mode2"])
 def test_full_size_frames_match_committed_hashes(ctx, V, golden, product_scenes, key):
     """BASELINE.json sizes: the oracle's frame hashes were committed by tests/golden/make_golden.py."""
     g = golden["frames"]["frames"][key]
@@ -277,6 +281,37 @@ def test_procedural_terrain_config4(ctx, V, O, golden, product_scenes):
     # the texel limit itself is enforced
     with pytest.raises(V.VrtError, match="2\\^23"):
         ctx.upload_octree(np.zeros(4 * (2 ** 23 + 1), np.uint8), 204)
+
+
+def test_terrain_config4_at_its_full_extent_through_records(ctx, V, golden):
+    """BASELINE config 4 as named: the WHOLE 1024 x 1024 height field (24.07 M texels' worth, 8.5 M records) -- beyond what
+    the reference's 23-bit pointer texels address, so the product takes it as records (vrth_world_records ->
+    vrt_upload_records) and the oracle read it through its wide-pointer stream extension (tests/golden/make_golden.py,
+    oracle.h); the frames must equal the oracle's committed hashes in all three modes, and the displayed frame too."""
+    from conftest import terrain_world
+    w = terrain_world(V, {"x0": 0, "z0": 0, "nx": 1024, "nz": 1024})
+    assert w.texel_count() == 24071648 and w.texel_count() > 2 ** 23
+    rec, dim = w.records()
+    w.close()
+    assert dim == 289
+    ctx.set_params(ctx.default_params())
+    ctx.upload_records(rec, dim)
+    frames = golden["frames"]["frames"]
+    for key in ("terrain_full_240x136/mode0", "terrain_full_240x136/mode1", "terrain_full_240x136/mode2",
+                "terrain_full_1080p/mode0", "terrain_full_1080p/mode1", "terrain_full_1080p_full/mode2"):
+        g = frames[key]
+        W, H = g["width"], g["height"]
+        ip, iv, cp, _ = V.camera_block(g["pose"][:3], g["pose"][3], g["pose"][4], W, H)
+        ctx.set_camera(ip, iv, cp)
+        for v in ((0, 1, 4, 20) if W < 1000 else (0,)):
+            ctx.set_variant(v)
+            rgba, idd = ctx.dispatch(W, H, g["mode"])
+            assert "%016x" % V.fnv1a64(rgba) == g["rgba_fnv1a64"], (key, v)
+            assert "%016x" % V.fnv1a64(idd) == g["id_dist_fnv1a64"], (key, v)
+        ctx.set_variant(0)
+        if "shown_fnv1a64" in g:
+            assert "%016x" % V.fnv1a64(ctx.denoise(rgba, idd)) == g["shown_fnv1a64"], key + " display pass"
+    assert ctx.scene_info()["n_records"] == rec.shape[0]
 
 
 def test_denoise_pass_matches_quad_frag_restatement(ctx, V, O, product_scenes):

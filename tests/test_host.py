@@ -58,6 +58,33 @@ def test_terrain_config4_flatten_matches_oracle_and_fixture(V, O, golden, produc
         os.remove(tmp)
 
 
+def test_room_scene_flattens_like_the_oracle(V, O, golden, product_scenes):
+    """The reference's translucent room (tests/golden/room.npz): the product's builder + flattener against the oracle's on
+    the same ordered insert list (overwrites at the wall corners, glass / jelly materials, alpha < 255)."""
+    from conftest import room_tree
+    tex, dim = product_scenes["room"]
+    otex, odim = O.flatten(room_tree(O))
+    assert dim == odim and np.array_equal(tex, otex)
+    assert golden["room"]["inserts"] == 12800
+    leaves = tex.reshape(-1, 4)
+    assert {40, 100} <= set(np.unique(leaves[:, 3]).tolist())        # glass and jelly alphas are in the stream
+    assert {int(np.float32(1.5) * np.float32(85.0)), int(np.float32(1.38) * np.float32(85.0))} <= set(np.unique(leaves[:, 0]).tolist())
+
+
+def test_wide_pointer_stream_is_the_reference_stream_below_2_23(O):
+    """The oracle's non-reference stream extension (oracle.h: o_scene.wide_pointers) changes nothing for trees the
+    reference's 23-bit pointers can address: same bytes, same frame, same fetch counts."""
+    tree, ok, _ = O.load_vox(os.path.join(MAPS, "monu9.vox"))
+    assert ok
+    a, d = O.flatten(tree)
+    b, d2 = O.flatten(tree, wide=True)
+    assert d == d2 and np.array_equal(a, b)
+    (ip, iv, cp), _ = O.camera_ubo((48.5, 60.5, 170.5), -90.0, -12.0, 96, 54)
+    r1 = O.render(O.make_scene(a, d, ip, iv, cp), 96, 54, 2)
+    r2 = O.render(O.make_scene(a, d, ip, iv, cp, wide=True), 96, 54, 2)
+    assert np.array_equal(r1[0], r2[0]) and np.array_equal(r1[1], r2[1]) and r1[3] == r2[3]
+
+
 def test_camera_block_bits(V, golden):
     for c in golden["camera"]["cases"]:
         ip, iv, cp, fr = V.camera_block([_f(x) for x in c["pos"]], _f(c["yaw"]), _f(c["pitch"]), c["width"], c["height"])

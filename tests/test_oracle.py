@@ -42,7 +42,17 @@ def test_small_frames_match_committed_hashes(O, golden):
         if g["width"] * g["height"] > 64 * 1024:
             continue
         if g["map"] not in scenes:
-            if g["map"] == "terrain":   # BASELINE config 4: the height-field fixture (tests/golden/make_terrain.py)
+            if g["map"] == "terrain_full":   # the whole field through the wide-pointer stream (extension, oracle.h); ~10 s
+                t = golden["terrain"]
+                tree = O.new_tree()
+                O.fill_heights(tree, np.load(os.path.join(os.path.dirname(MAPS), "terrain_heights.npz"))["heights"],
+                               0, 0, 1024, 1024, t["band"], t["floor"])
+                scenes[g["map"]] = O.flatten(tree, wide=True)
+                O.lib().o_octree_delete(tree)
+            elif g["map"] == "room":
+                from conftest import room_tree
+                tree = room_tree(O)
+            elif g["map"] == "terrain":   # BASELINE config 4: the height-field fixture (tests/golden/make_terrain.py)
                 t = golden["terrain"]
                 tree, wd = O.new_tree(), t["window"]
                 O.fill_heights(tree, np.load(os.path.join(os.path.dirname(MAPS), "terrain_heights.npz"))["heights"],
@@ -50,11 +60,12 @@ def test_small_frames_match_committed_hashes(O, golden):
             else:
                 tree, ok, _ = O.load_vox(os.path.join(MAPS, g["map"] + ".vox"))
                 assert ok, g["map"]
-            scenes[g["map"]] = O.flatten(tree)
+            if g["map"] not in scenes:
+                scenes[g["map"]] = O.flatten(tree)
         tex, dim = scenes[g["map"]]
         p = g["pose"]
         (ip, iv, cp), _ = O.camera_ubo(p[:3], p[3], p[4], g["width"], g["height"])
-        rgba, idd, _, st = O.render(O.make_scene(tex, dim, ip, iv, cp), g["width"], g["height"], g["mode"])
+        rgba, idd, _, st = O.render(O.make_scene(tex, dim, ip, iv, cp, wide=g["map"] == "terrain_full"), g["width"], g["height"], g["mode"])
         assert "%016x" % O.fnv1a64(rgba) == g["rgba_fnv1a64"], key
         assert "%016x" % O.fnv1a64(idd) == g["id_dist_fnv1a64"], key
         assert st["fetches"] == g["fetches"] and st["hits"] == g["hits"], key
