@@ -68,7 +68,7 @@ def parse_args(argv=None):
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ray-tables", action="store_true",
-                    help="A/B: every launch runs the shader's own ray-generation prologue (vrt_debug_set_ray_tables(0))")
+                    help="A/B: every launch runs the shader's own ray-generation prologue (vrt_set_option(VRT_OPT_RAY_TABLES, 0))")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket launches with hipEvents (roofline is then omitted); for measuring their cost")
     ap.add_argument("--gather", default="auto", choices=["auto", "final", "frame"],

@@ -291,6 +291,30 @@ int vrt_variant_available(int variant);
  * one-view launches of the default variant in all three modes and to vrt_denoise / vrt_dispatch_frame. */
 int vrt_set_tile_scheduling(vrt_ctx *ctx, int period);
 
+/* Switches of the dispatcher. Pixels never depend on them: both settings of each are held to the same oracle frames by the parity
+ * suite, which is what they exist for (and for A/B timing).
+ *   VRT_OPT_RAY_TABLES     1 (default): views whose inverse projection has the shape of a perspective or orthographic matrix read the
+ *                          per-column / per-row part of ray generation (raytracing.comp:626-634) from tables made once per projection;
+ *                          0: every launch runs the shader's own prologue.
+ *   VRT_OPT_EMPTY_OCTANTS  1 (default): when the tree is empty outside one aligned cube (every scene loaded at the origin of the
+ *                          reference's [-1023,1024)^3 world), rays that leave it end there and the deepest node that still holds
+ *                          everything stands in for the root; 2: the same without the tighter root; 0: off (rays walk the empty octants).
+ *   VRT_OPT_DISPLAY_KERNEL 0 (default): the display pass sums two pixels per lane; 1: one pixel per lane (round 1's kernel; exists in
+ *                          `make AB=1` builds only, VRT_E_INVALID otherwise). */
+#define VRT_OPT_RAY_TABLES 1
+#define VRT_OPT_EMPTY_OCTANTS 2
+#define VRT_OPT_DISPLAY_KERNEL 3
+int vrt_set_option(vrt_ctx *ctx, int option, int value);
+
+/* The feedback scheduler's order, read and overridden. vrt_get_tile_order copies the current workgroup-group order for the shape last
+ * launched on `stream` (NULL: the context's) into out[cap] and returns the number of groups (0 while no order has been derived).
+ * vrt_set_tile_order(enable = 1) makes one-view launches of the default kernel take caller-owned DEVICE buffers instead of the
+ * scheduler's: d_group_order (a permutation of the launch's groups of four 8x8 tiles, or NULL: row-major) and d_tile_cost (one uint32
+ * per tile, receives each tile's clock ticks, or NULL); enable = 0 hands the launches back to the scheduler. Any permutation renders
+ * the same pixels. */
+long vrt_get_tile_order(vrt_ctx *ctx, void *stream, uint32_t *out, size_t cap);
+int vrt_set_tile_order(vrt_ctx *ctx, int enable, const void *d_group_order, void *d_tile_cost);
+
 const char *vrt_version(void);
 
 #ifdef __cplusplus

@@ -536,7 +536,7 @@ def test_malformed_texel_streams_are_refused_or_laid_out_never_crash(V, product_
 
 
 def test_ray_table_is_the_shader_formula_per_column_and_row(V):
-    """vrt_debug_ray_table (what the dispatcher uploads for the kernels' table-driven prologue) against the shader's
+    """vrt_test_ray_table (what the dispatcher uploads for the kernels' table-driven prologue) against the shader's
     operations in numpy float32 (IEEE, like the host code): u = px / W * 2 - 1, invProjection * (u, v, -1, 1) with the
     association of mat_vec(), division by w (comp:626-634). Refusals: projections whose x depends on v, whose w varies,
     whose zero terms change sign over the frame, non-finite entries."""
@@ -581,7 +581,7 @@ def test_ray_table_is_the_shader_formula_per_column_and_row(V):
 
 
 def test_dispatcher_knows_when_the_world_is_empty_outside_wide_root_0(V, product_scenes):
-    """vrt_debug_root0: the dispatcher's two findings about a tree (KArgs::root0_only and the per-launch choice of wide
+    """vrt_test_root0: the dispatcher's two findings about a tree (KArgs::root0_only and the per-launch choice of wide
     root 0). The shipped maps sit in the octant [0, 1024)^3 and nothing else exists: root0_only; dragon.vox fills only the
     cell [0, 256)^3 of it, whose 64-unit cells it spreads over, so that cube becomes root 0 for an eye inside it and the
     octant stays root 0 for an eye outside. A voxel in another octant, or a second occupied 256-cell, ends either finding."""

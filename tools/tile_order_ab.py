@@ -34,13 +34,13 @@ def main():
     buf = plan.local_buffer(dev)
     p = plan.pointers(buf)
     L = ctx._L
-    L.vrt_debug_set_tile_order.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.vrt_set_tile_order.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     n_tiles = (W // 8) * (H // 8)
     n_wg = n_tiles // 4
 
     def run(label, order, ref=None, sched=0):
         ctx.set_tile_scheduling(sched)
-        L.vrt_debug_set_tile_order(ctx._h, 1 if order is not None else 0, order.data_ptr() if order is not None else None, None)
+        L.vrt_set_tile_order(ctx._h, 1 if order is not None else 0, order.data_ptr() if order is not None else None, None)
         buf.zero_()
         for _ in range(40):
             ctx.dispatch_shard(W, H, 8, 0, 1, 0, p[0], p[1], st.cuda_stream)
@@ -60,7 +60,7 @@ def main():
 
     ref = run("plain kernel", None)
     cost = torch.zeros(n_tiles, dtype=torch.int32, device=dev)
-    L.vrt_debug_set_tile_order(ctx._h, 1, None, cost.data_ptr())
+    L.vrt_set_tile_order(ctx._h, 1, None, cost.data_ptr())
     ctx.dispatch_shard(W, H, 8, 0, 1, 0, p[0], p[1], st.cuda_stream)
     torch.cuda.synchronize()
     c = cost.cpu().numpy().astype(np.int64) & 0xffffffff

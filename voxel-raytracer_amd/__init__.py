@@ -19,6 +19,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 HIP_LIB = os.path.join(HERE, "libvrt_hip.so")
 HOST_LIB = os.path.join(HERE, "libvrt_host.so")
+TEST_LIB = os.path.join(HERE, "libvrt_hip_test.so")   # test support, not product (csrc/test/vrt_test.hip)
+OPT_RAY_TABLES, OPT_EMPTY_OCTANTS, OPT_DISPLAY_KERNEL = 1, 2, 3
 
 MODE_PRIMARY, MODE_PRIMARY_SHADOW, MODE_FULL = 0, 1, 2
 MODES = {"primary": MODE_PRIMARY, "primary_shadow": MODE_PRIMARY_SHADOW, "full": MODE_FULL}
@@ -28,9 +30,9 @@ class VrtError(RuntimeError):
     pass
 
 
-def build(targets=("../libvrt_hip.so", "../libvrt_host.so")):
+def build(targets=("../libvrt_hip.so", "../libvrt_hip_test.so", "../libvrt_host.so")):
     """Compile the libraries in-tree (hipcc --offload-arch=gfx950 / g++)."""
-    subprocess.check_call(["make", "-C", CSRC, *targets])
+    subprocess.check_call(["make", "-j8", "-C", CSRC, *targets])
 
 
 class Params(C.Structure):
@@ -133,7 +135,10 @@ def hip_lib():
         L.vrt_synchronize.argtypes = [C.c_void_p]
         L.vrt_denoise.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vrt_denoise_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.vrt_debug_set_denoise_variant.argtypes = [C.c_void_p, C.c_int]
+        L.vrt_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.vrt_get_tile_order.restype = C.c_long
+        L.vrt_get_tile_order.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.vrt_set_tile_order.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.vrt_dispatch_views.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(View), C.c_int, C.c_void_p]
         L.vrt_patch_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Patch)]
@@ -180,16 +185,43 @@ def hip_lib():
         L.vrt_multi_synchronize.argtypes = [C.c_void_p]
         L.vrt_multi_stream.restype = C.c_void_p
         L.vrt_multi_stream.argtypes = [C.c_void_p]
-        L.vrt_debug_set_full_split.argtypes = [C.c_void_p, C.c_int]
-        L.vrt_debug_set_ray_tables.argtypes = [C.c_void_p, C.c_int]
-        L.vrt_debug_set_root0_only.argtypes = [C.c_void_p, C.c_int]
-        L.vrt_debug_set_bounce.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.vrt_version.restype = C.c_char_p
-        L.vrt_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
-        L.vrt_debug_build_layout.restype = C.c_long
-        L.vrt_debug_build_layout.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(SceneInfo)]
+        if hasattr(L, "vrt_ab_set_full_split"):   # `make AB=1` builds only
+            L.vrt_ab_set_full_split.argtypes = [C.c_void_p, C.c_int]
+            L.vrt_ab_set_bounce.argtypes = [C.c_void_p, C.c_int, C.c_int]
         _hip = L
     return _hip
+
+
+_test = None
+
+
+def test_lib():
+    """libvrt_hip_test.so: device probes of the kernels' arithmetic and host-only views of the uploader's layouts, for the
+    parity suite (csrc/test/vrt_test.hip). Not part of the product; libvrt_hip.so exports none of it."""
+    global _test
+    if _test is None:
+        if not os.path.exists(TEST_LIB):
+            raise VrtError(f"{TEST_LIB} is missing: make -C {CSRC}")
+        try:
+            import torch  # noqa: F401  (one HIP runtime per process, see hip_lib())
+        except ImportError:
+            pass
+        L = C.CDLL(TEST_LIB)
+        L.vrt_test_math.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.vrt_test_build_layout.restype = C.c_long
+        L.vrt_test_build_layout.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(SceneInfo)]
+        L.vrt_test_patch_check.restype = C.c_long
+        L.vrt_test_patch_check.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                           C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        L.vrt_test_ray_table.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vrt_test_root0.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                     C.POINTER(C.c_int32)]
+        L.vrt_test_view_in_range.argtypes = [C.c_void_p]
+        L.vrt_test_wide_find.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p,
+                                         C.c_size_t, C.c_void_p, C.c_void_p]
+        _test = L
+    return _test
 
 
 def available_variants(upto=64):
@@ -336,92 +368,82 @@ def fnv1a64(arr):
 
 def build_layout(texels):
     """Host-only: the device record array the uploader would build -> (uint32[n,2], SceneInfo)."""
-    L = hip_lib()
+    L = test_lib()
     t = np.ascontiguousarray(texels, np.uint8)
     info = SceneInfo()
-    n = L.vrt_debug_build_layout(t.ctypes.data if t.size else None, t.size, None, 0, C.byref(info))
+    n = L.vrt_test_build_layout(t.ctypes.data if t.size else None, t.size, None, 0, C.byref(info))
     if n < 0:
         raise VrtError("malformed texel stream")
     rec = np.zeros((n, 2), np.uint32)
-    L.vrt_debug_build_layout(t.ctypes.data if t.size else None, t.size, rec.ctypes.data, n, None)
+    L.vrt_test_build_layout(t.ctypes.data if t.size else None, t.size, rec.ctypes.data, n, None)
     return rec, info
 
 
 def patch_check(texels_before, texels_after, voxel, points, world_min=(-1023, -1023, -1023), world_max=(1024, 1024, 1024),
                 sparse=False):
-    """Host-only (vrt_debug_patch_check): patch the layouts of the tree before an edit of `voxel` with the sub-tree of
+    """Host-only (vrt_test_patch_check): patch the layouts of the tree before an edit of `voxel` with the sub-tree of
     the tree after it and compare point lookups with freshly built layouts.
     -> (mismatching points, depth of the node replaced or 0, records appended, wide cells appended, texel count ok)"""
-    L = hip_lib()
-    L.vrt_debug_patch_check.restype = C.c_long
-    L.vrt_debug_patch_check.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
-                                        C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+    L = test_lib()
     tb = np.ascontiguousarray(texels_before, np.uint8)
     ta = np.ascontiguousarray(texels_after, np.uint8)
     pts = np.ascontiguousarray(points, np.int32).reshape(-1, 3)
     info = np.zeros(4, np.uint32)
-    r = L.vrt_debug_patch_check(tb.ctypes.data if tb.size else None, tb.size, ta.ctypes.data if ta.size else None, ta.size,
+    r = L.vrt_test_patch_check(tb.ctypes.data if tb.size else None, tb.size, ta.ctypes.data if ta.size else None, ta.size,
                                 (C.c_int32 * 3)(*world_min), (C.c_int32 * 3)(*world_max), int(voxel[0]), int(voxel[1]),
                                 int(voxel[2]), pts.ctypes.data, pts.shape[0], info.ctypes.data, 1 if sparse else 0)
     if r < 0:
-        raise VrtError(f"vrt_debug_patch_check failed ({r})")
+        raise VrtError(f"vrt_test_patch_check failed ({r})")
     return int(r), int(info[0]), int(info[1]), int(info[2]), bool(info[3])
 
 
 def ray_table(inv_projection, width, height):
-    """Host-only: the per-column / per-row ray-generation table of a projection (vrt_debug_ray_table)
+    """Host-only: the per-column / per-row ray-generation table of a projection (vrt_test_ray_table)
     -> (x[width], y[height], z) float32, or None when the projection has no table."""
-    L = hip_lib()
-    L.vrt_debug_ray_table.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L = test_lib()
     m = np.ascontiguousarray(inv_projection, np.float32).reshape(16)
     x, y, z = np.zeros(width, np.float32), np.zeros(height, np.float32), np.zeros(1, np.float32)
-    r = L.vrt_debug_ray_table(m.ctypes.data, width, height, x.ctypes.data, y.ctypes.data, z.ctypes.data)
+    r = L.vrt_test_ray_table(m.ctypes.data, width, height, x.ctypes.data, y.ctypes.data, z.ctypes.data)
     if r < 0:
-        raise VrtError(f"vrt_debug_ray_table failed ({r})")
+        raise VrtError(f"vrt_test_ray_table failed ({r})")
     return (x, y, float(z[0])) if r == 1 else None
 
 
 def root0_choice(texels, eye, world_min=(-1023, -1023, -1023), world_max=(1024, 1024, 1024)):
-    """Host-only (vrt_debug_root0): (root0_only, log2 side of the root chosen for this eye, its minimum corner (3), log2 side
+    """Host-only (vrt_test_root0): (root0_only, log2 side of the root chosen for this eye, its minimum corner (3), log2 side
     of build_wide()'s root), or None when the scene has no wide form."""
-    L = hip_lib()
-    L.vrt_debug_root0.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
-                                  C.POINTER(C.c_int32)]
+    L = test_lib()
     t = np.ascontiguousarray(texels, np.uint8)
     out = (C.c_int32 * 6)()
-    r = L.vrt_debug_root0(t.ctypes.data if t.size else None, t.size, (C.c_int32 * 3)(*world_min), (C.c_int32 * 3)(*world_max),
+    r = L.vrt_test_root0(t.ctypes.data if t.size else None, t.size, (C.c_int32 * 3)(*world_min), (C.c_int32 * 3)(*world_max),
                           (C.c_int32 * 3)(*[int(v) for v in eye]), out)
     if r == -5:
         return None
     if r != 0:
-        raise VrtError(f"vrt_debug_root0 failed ({r})")
+        raise VrtError(f"vrt_test_root0 failed ({r})")
     return bool(out[0]), int(out[1]), (int(out[2]), int(out[3]), int(out[4])), int(out[5])
 
 
 def view_in_range(inv_view):
-    L = hip_lib()
-    L.vrt_debug_view_in_range.argtypes = [C.c_void_p]
     m = np.ascontiguousarray(inv_view, np.float32).reshape(16)
-    return L.vrt_debug_view_in_range(m.ctypes.data) == 1
+    return test_lib().vrt_test_view_in_range(m.ctypes.data) == 1
 
 
 def wide_find(texels, points, world_min=(-1023, -1023, -1023), world_max=(1024, 1024, 1024)):
     """Host-only: point queries through the wide (64-cell) layout the default kernels read.
     -> (uint32[n,8] = w0, w1, mn[3], mx[3], (wide nodes, roots)), or None when the scene has no wide form."""
-    L = hip_lib()
-    L.vrt_debug_wide_find.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p,
-                                      C.c_size_t, C.c_void_p, C.c_void_p]
+    L = test_lib()
     t = np.ascontiguousarray(texels, np.uint8)
     pts = np.ascontiguousarray(points, np.int32).reshape(-1, 3)
     out = np.zeros((pts.shape[0], 8), np.uint32)
     stats = np.zeros(2, np.uint32)
-    r = L.vrt_debug_wide_find(t.ctypes.data if t.size else None, t.size, (C.c_int32 * 3)(*world_min),
+    r = L.vrt_test_wide_find(t.ctypes.data if t.size else None, t.size, (C.c_int32 * 3)(*world_min),
                               (C.c_int32 * 3)(*world_max), pts.ctypes.data, pts.shape[0], out.ctypes.data,
                               stats.ctypes.data)
     if r == -5:
         return None
     if r != 0:
-        raise VrtError(f"vrt_debug_wide_find failed ({r})")
+        raise VrtError(f"vrt_test_wide_find failed ({r})")
     return out, (int(stats[0]), int(stats[1]))
 
 
@@ -644,26 +666,35 @@ class Context:
         self._chk(self._L.vrt_set_tile_scheduling(self._h, period))
 
     def sched_order(self, stream=None, cap=1 << 20):
-        """The scheduler's current workgroup order for the shape last launched on `stream` (vrt_debug_sched_order);
+        """The scheduler's current workgroup order for the shape last launched on `stream` (vrt_get_tile_order);
         empty until an order has been derived."""
-        self._L.vrt_debug_sched_order.restype = C.c_long
-        self._L.vrt_debug_sched_order.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         buf = np.zeros(cap, np.uint32)
-        n = self._L.vrt_debug_sched_order(self._h, stream, buf.ctypes.data, cap)
+        n = self._L.vrt_get_tile_order(self._h, stream, buf.ctypes.data, cap)
         if n < 0:
             self._chk(n)
         return buf[:min(n, cap)].copy()
 
+    def set_option(self, option, value):
+        self._chk(self._L.vrt_set_option(self._h, option, value))
+
+    def set_tile_order(self, enable, d_group_order=None, d_tile_cost=None):
+        """caller-owned device buffers for the default kernel's group order / per-tile ticks (vrt_set_tile_order)"""
+        self._chk(self._L.vrt_set_tile_order(self._h, 1 if enable else 0, d_group_order, d_tile_cost))
+
     def set_full_split(self, on):
-        """A/B: the full path tracer as two kernels (default) or as round 1's one kernel"""
-        self._chk(hip_lib().vrt_debug_set_full_split(self._h, 1 if on else 0))
+        """`make AB=1` builds: the full path tracer as two kernels with cross-wave repacking (off by default)"""
+        if not hasattr(self._L, "vrt_ab_set_full_split"):
+            if on:
+                raise VrtError("the two-kernel full path tracer exists in A/B builds only (make AB=1)")
+            return
+        self._chk(self._L.vrt_ab_set_full_split(self._h, 1 if on else 0))
 
     def set_bounce(self, refill_below, waves_per_simd):
-        self._chk(hip_lib().vrt_debug_set_bounce(self._h, refill_below, waves_per_simd))
+        self._chk(self._L.vrt_ab_set_bounce(self._h, refill_below, waves_per_simd))
 
     def set_denoise_variant(self, v):
-        """Pixels per lane of the display-pass kernel: 0 = two (default), 1 = one."""
-        self._chk(self._L.vrt_debug_set_denoise_variant(self._h, v))
+        """Pixels per lane of the display-pass kernel: 0 = two (default), 1 = one (A/B builds only)."""
+        self.set_option(OPT_DISPLAY_KERNEL, v)
 
     def synchronize(self):
         self._chk(self._L.vrt_synchronize(self._h))
@@ -674,17 +705,20 @@ class Context:
 
     def set_root0_only(self, on):
         """A/B: False = rays that leave wide root 0 always walk the records of the octants around it"""
-        self._chk(hip_lib().vrt_debug_set_root0_only(self._h, int(on)))   # True/1: on, 2: on without the tighter root, False/0: off
+        self.set_option(OPT_EMPTY_OCTANTS, int(on))   # True/1: on, 2: on without the tighter root, False/0: off
 
     def set_ray_tables(self, on):
         """A/B: False = every launch runs the shader's own ray-generation prologue (no per-projection tables)"""
-        self._chk(hip_lib().vrt_debug_set_ray_tables(self._h, 1 if on else 0))
+        self.set_option(OPT_RAY_TABLES, 1 if on else 0)
 
     def debug_math(self, op, x, y):
+        """device probe of the kernels' arithmetic (test support library, vrt_test_math) on this context's device"""
         x = np.ascontiguousarray(x, np.float32)
         y = np.ascontiguousarray(y, np.float32)
         out = np.zeros_like(x)
-        self._chk(self._L.vrt_debug_math(self._h, op, x.ctypes.data, y.ctypes.data, out.ctypes.data, x.size))
+        r = test_lib().vrt_test_math(self._L.vrt_device(self._h), op, x.ctypes.data, y.ctypes.data, out.ctypes.data, x.size)
+        if r != 0:
+            raise VrtError(f"vrt_test_math failed ({r})")
         return out
 
 

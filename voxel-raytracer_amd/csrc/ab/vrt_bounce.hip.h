@@ -17,8 +17,8 @@
 // The per-ray arithmetic is the march of vrt_kernels_v4.hip.h and the depth >= 1 shading of trace_pixel_full, operation
 // for operation, so the pixels are the ones the one-kernel form writes (tests/test_gpu_parity.py).
 #pragma once
-#include "vrt_full.hip.h"
-#include "vrt_kernels_v4.hip.h"
+#include "../vrt_full.hip.h"
+#include "../vrt_kernels_v4.hip.h"
 
 namespace vrt {
 namespace bounce {

@@ -12,101 +12,10 @@
 //     node lookup may use any structure because octreeFind's result is a pure
 //     function of the query point (the deepest node containing it).
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+
+#include "vrt_args.h"
 
 namespace vrt {
-
-struct F3 { float x, y, z; };
-struct I3 { int x, y, z; };
-
-// One camera and the two images it renders into. A launch carries up to kMaxViews of them (blockIdx.y selects
-// the view): frames of one scene that are known together -- a stereo pair, the next frames of a camera path, the
-// views of a light-field rig -- share one launch, so the drain of one view's last waves is filled by the next
-// view's first instead of idling the chip between launches.
-constexpr int kMaxViews = 4;
-constexpr int kGroupTiles = 4;  // tiles per scheduling group: 4 adjacent 8x8 tiles, i.e. 32 x 8 pixels
-struct View {
-    float inv_proj[16];
-    float inv_view[16];
-    float cam_pos[4];
-    uint32_t *out_rgba;       // packed R | G<<8 | B<<16 | A<<24
-    int2 *out_id;             // (voxelID, dist)
-    uint32_t eye0, eye1;      // raw leaf words of the node that holds the eye (comp:445-449), looked up by the host
-    // the primary rays' first lookup (at the eye), made by the host for the wide kernels (vrt_layout.h first_find)
-    uint32_t first_w0, first_w1, first_node, first_anode;
-    int first_s, first_as, first_valid;
-    // Ray generation with its per-column and per-row parts made once per projection by the dispatcher (ray_table() in
-    // vrt_capi.hip): when the inverse projection has the shape every perspective or orthographic matrix gives it -- x
-    // depends on the column only, y on the row only, z and w on neither -- gen_x[px], gen_y[py], gen_z hold view.xyz / w
-    // of comp:630-634 (same float operations, made on the host), and gen_fast says that they do and that every
-    // normalisation of the prologue stays inside the range where 1/x and sqrt need no range scaling (primary_ray_dir()).
-    const float *gen_x, *gen_y;
-    float gen_z;
-    uint32_t gen_fast;
-};
-
-// Kernel arguments: passed by value (kernarg segment -> scalar loads, wave-uniform).
-// The views of a launch: a kernel argument of its own. Indexed by blockIdx.y inside KArgs it made the compiler
-// treat every argument as dynamically addressed and keep them live (88 instead of 69 VGPRs on gfx950, through SGPR
-// spills into vector lanes); on its own it costs nothing.
-struct ViewSet {
-    View v[kMaxViews];
-};
-
-struct KArgs {
-    int n_views;              // gridDim.y
-    float voxel_scale;
-    int wmin[3];
-    int wmax[3];
-    float global_light[4];
-    float light_dir[3];
-    // the shadow ray's set-up (comp:335-345), the same for every ray of a launch: made by the dispatcher from light_dir
-    // with the shader's operations -- 1/d or 1e20, sign * 1e-3, d > 0 -- instead of 70 vector instructions per wave
-    float light_inv[3], light_push[3], light_dposf[3];
-    int light_dpos[3];
-    int shade_fast;           // globalLight and lightDir are finite and at most 2^30: the shading quotients x / PI are in range (div_pi_inrange())
-    int highlighted[3];
-    int tex_dim;
-    int width, height;
-    // rows traced by this launch: local row j in [0, n_rows) maps to frame row
-    //   y = row0 + (j / tile_rows) * row_stride + (j % tile_rows)
-    int row0, n_rows, tile_rows, row_stride;
-    int compact;              // 1: outputs indexed by local row j, 0: by frame row y
-    // the two index divisions of a wave's prologue, prepared by the host (enqueue() in vrt_capi.hip):
-    uint32_t tiles_x_magic;   // floor(2^32 / tiles_x) + 1 when tile / tiles_x == umulhi(tile, magic) for every tile, else 0
-    int row_mode;             // 1: one row tile (y = row0 + j); 2: tile_rows == 8 == tile height (y = row0 + ty * row_stride + ly); 0: divide
-    const uint2 *nodes;       // level-ordered records (vrt_layout.h), root = record 0
-    uint32_t n_records;
-    uint32_t lds_records;     // prefix of `nodes` staged in LDS by each workgroup
-    // wide layout (vrt_layout.h): 64 cells per node; roots = octree records where a wide tree starts
-    const uint2 *cells;
-    const uint2 *cells4;      // the same cells in the form of the v4 kernels (vrt_layout.h to_cell4)
-    uint32_t n_roots;
-    // wide roots: [0..7] octree record of each root, [8..15] its wide node (device memory; read only by the record
-    // walk that a lookup outside wide root 0 takes). Root 0's node and log2 side also travel by value.
-    const uint32_t *root_table;
-    uint32_t root0_node;
-    int root0_shift;
-    int root0_min[3];         // minimum corner of wide root 0's cube (valid when n_roots > 0)
-    int root0_only;           // 1: every record outside wide root 0's subtree is an absent child -- the world is empty outside that cube
-    // Feedback scheduling (SCHED flavours of trace_kernel; vrt_capi.hip owns the buffers). The unit is a GROUP of
-    // kGroupTiles consecutive tiles. bit 0: the g-th group of tiles the launch starts is group_order[g] (a permutation
-    // of the launch's groups, heaviest first). bit 1: every wave leaves the clock ticks its tile took in
-    // tile_cost[tile], from which tile_order_kernel derives the next order.
-    const uint32_t *group_order;
-    uint32_t *tile_cost;
-    // Deferred diffuse bounces of the full path tracer (MODE 3 of trace_kernel, vrt_bounce.hip.h): kDeferQueues queues of
-    // defer_cap ray records each, structure of arrays (plane p of queue q starts at defer_rec + (p * kDeferQueues + q) * defer_cap),
-    // defer_count[q * kDeferStride] = records in queue q, defer_count[(kDeferQueues + q) * kDeferStride] = records already
-    // handed out by bounce_kernel: every counter in a cache line of its own (atomics on one line are served one at a time).
-    float *defer_rec;
-    uint32_t *defer_count;
-    uint32_t defer_cap;
-};
-constexpr uint32_t kDeferQueues = 64;   // a wave appends to queue (tile % 64): sixty-four counters share the atomic traffic
-constexpr uint32_t kDeferStride = 64;   // words between two counters: 256 bytes
-constexpr uint32_t kDeferPlanes = 19;   // o[3] d[3] tint[3] fc[3] iof weight mc[3] md out_offset
 
 #define VRT_DEV __device__ __forceinline__
 
@@ -515,110 +424,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
         }
         if constexpr (!PERSIST) break;
     }
-}
-
-// Feedback scheduling, second half: turns the per-tile ticks of one frame into the group order of the next ones.
-// The hardware starts workgroups in index order, and a launch ends when its last-started, slowest workgroups drain; started
-// heaviest first, the tail consists of the cheapest tiles instead (longest-processing-time-first list scheduling). A
-// group's cost is the maximum over its kGroupTiles tiles; groups are bucketed by cost (256 linear buckets up to the
-// frame's maximum) and written out from the heaviest bucket down. One workgroup of 1024 lanes; any permutation is
-// correct for the trace kernel, the costs only decide how good it is.
-__global__ __launch_bounds__(1024) void tile_order_kernel(const uint4 *group_ticks, uint32_t n_groups, uint32_t *group_order) {
-    // group_ticks: the tile_cost words, kGroupTiles per group; the words past the launch's last tile are zero
-    static_assert(kGroupTiles == 4, "one 16-byte load per group");
-    extern __shared__ uint32_t group_cost[];  // n_groups
-    __shared__ uint32_t hist[256], top;
-    const uint32_t t = threadIdx.x;
-    if (t < 256) hist[t] = 0;
-    if (t == 0) top = 0;
-    __syncthreads();
-    uint32_t m = 0;
-    for (uint32_t base = 0; base < n_groups; base += 8 * 1024) {  // eight loads in flight per lane: one round trip per 8192 groups
-        uint4 v[8];
-#pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) {
-            const uint32_t g = base + u * 1024 + t;
-            v[u] = g < n_groups ? group_ticks[g] : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) {
-            const uint32_t g = base + u * 1024 + t;
-            const uint32_t c01 = v[u].x > v[u].y ? v[u].x : v[u].y, c23 = v[u].z > v[u].w ? v[u].z : v[u].w;
-            const uint32_t c = c01 > c23 ? c01 : c23;
-            if (g < n_groups) group_cost[g] = c;
-            m = c > m ? c : m;
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {  // one atomic per wave, not per lane
-        const uint32_t v = (uint32_t)__shfl_xor((int)m, off);
-        m = v > m ? v : m;
-    }
-    if ((t & 63u) == 0u) atomicMax(&top, m);
-    __syncthreads();
-    const uint32_t shift = top >= 256 ? 24 - (uint32_t)__builtin_clz(top) : 0;  // top >> shift <= 255
-    for (uint32_t g = t; g < n_groups; g += 1024) atomicAdd(&hist[group_cost[g] >> shift], 1u);
-    __syncthreads();
-    // hist[b] := first output slot of bucket b, heaviest bucket first: a suffix sum over the 256 counts, done by
-    // the first wave alone (lane l owns buckets 4l .. 4l+3) so that it costs one barrier instead of sixteen
-    if (t < 64) {
-        const uint32_t h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
-        const uint32_t own = h0 + h1 + h2 + h3;
-        uint32_t incl = own;  // becomes the sum over lanes >= t
-#pragma unroll
-        for (uint32_t off = 1; off < 64; off <<= 1) {
-            const uint32_t v = (uint32_t)__shfl_down((int)incl, off);
-            if (t + off < 64) incl += v;
-        }
-        const uint32_t above = incl - own;  // everything in heavier lanes
-        hist[4 * t + 3] = above;
-        hist[4 * t + 2] = above + h3;
-        hist[4 * t + 1] = above + h3 + h2;
-        hist[4 * t] = above + h3 + h2 + h1;
-    }
-    __syncthreads();
-    for (uint32_t g = t; g < n_groups; g += 1024) group_order[atomicAdd(&hist[group_cost[g] >> shift], 1u)] = g;
-}
-
-// late_args() / late_view() assume the kernarg segment holds KArgs at offset 0 and ViewSet behind it at its natural
-// alignment. The compiler's layout rules guarantee that for two by-value aggregates, and these keep it from drifting:
-static_assert(__is_trivially_copyable(KArgs) && __is_trivially_copyable(ViewSet), "kernel arguments are copied bytewise");
-static_assert(alignof(KArgs) <= 8 && alignof(ViewSet) <= 8, "by-value kernel arguments are laid out at their natural alignment (<= 8 here)");
-// ... and this probe checks it on the device once per context (vrt_create): every view's late pointers and a few late
-// uniforms against the by-value arguments. out[0] = number of mismatches.
-__global__ void kernarg_probe_kernel(const KArgs a, const ViewSet vs, uint32_t *out) {
-    const LateArgs la = late_args();
-    const LateView lv = late_view();
-    const View &v = vs.v[blockIdx.y];
-    uint32_t bad = 0;
-    bad += la->width != a.width || la->height != a.height || la->tex_dim != a.tex_dim || la->compact != a.compact;
-    bad += la->light_dir[2] != a.light_dir[2] || la->highlighted[1] != a.highlighted[1] || la->voxel_scale != a.voxel_scale;
-    bad += lv->out_rgba != v.out_rgba || lv->out_id != v.out_id || lv->cam_pos[1] != v.cam_pos[1];
-    if (threadIdx.x == 0 && bad) atomicAdd(out, bad);
-}
-
-// exactness probe for the arithmetic contract: out[i] = op(x[i], y[i])
-__global__ void math_probe_kernel(int op, const float *x, const float *y, float *out, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float a = x[i], b = y[i], r = 0.0f;
-    switch (op) {
-        case 0: r = a / b; break;
-        case 1: r = __builtin_sqrtf(a); break;
-        case 2: r = 1.0f / __builtin_sqrtf(a); break;
-        case 3: r = __builtin_floorf(a); break;
-        case 4: r = __builtin_rintf(a); break;
-        case 5: r = a * b + 1.0f; break;          // must NOT be fused
-        case 6: r = det_expf(a); break;
-        case 7: r = (float)(int)a; break;
-        case 8: r = a + b; break;
-        case 9: r = a * b; break;
-        case 30: r = rcp_inrange(a); break;
-        case 31: r = sqrt_inrange(a); break;
-        case 32: r = div_pi_inrange(a); break;
-        default: break;
-    }
-    out[i] = r;
 }
 
 }  // namespace vrt

@@ -347,22 +347,5 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
     lo.skip_rgba = deferred;
 }
 
-// exactness probe for the conventions above (ops 10..): out[i] = op(x[i], y[i])
-__global__ void math_probe_full_kernel(int op, const float *x, const float *y, float *out, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float a = x[i], b = y[i], r = 0.0f, s, c;
-    switch (op) {
-        case 10: det_sincos(a, s, c); r = s; break;
-        case 11: det_sincos(a, s, c); r = c; break;
-        case 12: r = det_powf(a, b); break;
-        case 13: { int q; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(q) : "v"(a)); r = (float)q; } break;
-        case 14: r = (float)__float_as_uint(a) / 4294967296.0f; break;  // rand(): uint -> float, RNE
-        case 15: r = unorm_of(a); break;                                // must equal a / 255.0f for the 256 byte values
-        default: break;
-    }
-    out[i] = r;
-}
-
 }  // namespace full
 }  // namespace vrt

@@ -23,7 +23,7 @@
 namespace vrt {
 namespace v3 {
 
-constexpr int kAnchorShift = 6;  // restart point: the wide node of side 64 the ray is in
+// kAnchorShift (vrt_args.h): the restart point, the wide node of side 64 the ray is in
 
 struct Walk {                 // per-ray lookup state carried from one find to the next
     uint32_t node; int s;     // current wide node and log2 of its side; s < 0: none

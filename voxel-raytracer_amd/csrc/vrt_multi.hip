@@ -75,7 +75,10 @@ int vrt_device_alloc(vrt_ctx *c, size_t bytes, void **d_ptr) {
     VRTC_HIP(hipSetDevice(vrt_device(c)));
     void *p = nullptr;
     VRTC_HIP(hipMalloc(&p, bytes));
-    if (hipMemset(p, 0, bytes) != hipSuccess) {
+    // zero-filled BEFORE the pointer is handed out: the memory is exported over IPC and written from non-blocking streams
+    // (flags, frame slots), which have no implicit ordering with a null-stream memset still in flight
+    hipStream_t s = (hipStream_t)vrt_stream(c);
+    if (hipMemsetAsync(p, 0, bytes, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
         (void)hipFree(p);
         return VRT_E_HIP;
     }
