@@ -8,7 +8,7 @@ tiles, and EVERY frame is delivered to rank 0 over RCCL inside the timed region 
 the rate with the frames left sharded in the ranks' HBM is printed beside it (`sharded_resident`).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode primary|primary_shadow|full]
-                    [--map dragon|monu9|nature|terrain] [--width 1920 --height 1080] [--variant V]
+                    [--map dragon|monu9|nature|terrain|terrain_full|room] [--width 1920 --height 1080] [--variant V]
 
 `--gpus N` with N > 1 and no torchrun environment starts the N ranks itself (a child
 `python -m torch.distributed.run --nproc-per-node N bench.py ...`, before this process touches the
@@ -24,6 +24,12 @@ With N > 1 the headline is the faster verified of two ways of delivering every f
 (`config.delivery`: an RCCL gather per frame, or the kernels' own stores through IPC mappings of
 rank 0's frame); both, the rotating-root form and the sharded-resident rate are in the line, and so is
 `whole_frame_per_gpu`: N whole frames per step, one per GPU, kept where they were traced (weak scaling).
+
+At one GPU the line also carries `configs`: every other BASELINE.json configuration (monu9 720p, the config-4 terrain at its
+full extent and as the window the texel format holds, nature 4K + shadow rays), the full path tracer, the displayed frame
+and the reference's translucent room, each timed the same way (pre-roll, W warm-up, K timed frames, hipEvent pairs on the
+kernel) and checked against the oracle's golden hashes, and config 1's CPU ray cast (the host library's octree_ray_cast,
+256 x 256). `--no-configs` leaves them out (profiling runs of the headline kernel).
 """
 import argparse
 import json
@@ -41,8 +47,24 @@ POSES = {  # framing poses of SURVEY.md 8(d): x, y, z, yaw, pitch
     "monu9": (48.5, 60.5, 170.5, -90.0, -12.0),
     "nature": (60.5, 80.5, 200.5, -90.0, -20.0),
     "terrain": (512.5, 420.5, 1000.5, -90.0, -20.0),  # config 4: tests/golden/terrain.json
+    "terrain_full": (512.5, 420.5, 1000.5, -90.0, -20.0),   # config 4 at its named extent (records path, no texel stream)
+    "room": (14.5, 30.5, 16.5, 32.0, -10.0),                # tests/golden/room.json "inside"
 }
-GOLDEN_KEY = {"dragon": "dragon_1080p", "monu9": "monu9_720p", "nature": "nature_4k", "terrain": "terrain_1080p"}
+GOLDEN_KEY = {"dragon": "dragon_1080p", "monu9": "monu9_720p", "nature": "nature_4k", "terrain": "terrain_1080p",
+              "terrain_full": "terrain_full_1080p", "room": "room_inside_1080p"}
+# the BASELINE.json configurations beside the headline one (configs[2]) and the rows SURVEY 8(f) added, in the order timed:
+# (name, map, width, height, mode); mode "shown" = full path tracer + display pass (what the reference puts on screen)
+CONFIGS = [
+    ("config2_monu9_720p_primary", "monu9", 1280, 720, "primary"),
+    ("config3_dragon_1080p_primary_shadow", "dragon", 1920, 1080, "primary_shadow"),
+    ("dragon_1080p_full_path_tracer", "dragon", 1920, 1080, "full"),
+    ("dragon_1080p_displayed_frame", "dragon", 1920, 1080, "shown"),
+    ("config5_nature_4k_primary_shadow", "nature", 3840, 2160, "primary_shadow"),
+    ("config4_terrain_window_1080p_primary", "terrain", 1920, 1080, "primary"),
+    ("config4_terrain_full_1080p_primary", "terrain_full", 1920, 1080, "primary"),
+    ("config4_terrain_full_1080p_primary_shadow", "terrain_full", 1920, 1080, "primary_shadow"),
+    ("room_inside_1080p_full_path_tracer", "room", 1920, 1080, "full"),
+]
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 KERNEL_SAMPLES = 16    # launches of the timed region that carry a hipEvent pair (every max(2, steps // 16)-th: >= 10 of 20)
 
@@ -67,6 +89,8 @@ def parse_args(argv=None):
     ap.add_argument("--tile-rows", type=int, default=8)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="one GPU: leave the `configs` array (the other BASELINE configurations) out of the line")
     ap.add_argument("--no-ray-tables", action="store_true",
                     help="A/B: every launch runs the shader's own ray-generation prologue (vrt_set_option(VRT_OPT_RAY_TABLES, 0))")
     ap.add_argument("--no-kernel-events", action="store_true",
@@ -156,10 +180,11 @@ def cpu_baseline(args, tex, dim, cam, budget_s=10.0):
     dt = time.perf_counter() - t0
     out = {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
            "sample": f"{rays} primary rays of the same frame ({passes} bands of {band} rows, cycling) in {dt:.1f} s, "
-                     f"oracle/rt_oracle.c -O2 -ffp-contract=off, 1 thread of {os.cpu_count()} host cores"}
+                     f"oracle/rt_oracle.c -O3 -ffp-contract=off, 1 thread; the box has {os.cpu_count()} logical CPUs, "
+                     f"{len(os.sched_getaffinity(0))} of them open to this process"}
     # the same port row-parallel: T threads, each tracing its own bands for ~mt_budget seconds
     import threading
-    T = max(1, min(16, os.cpu_count() or 1))
+    T = max(1, len(os.sched_getaffinity(0)))   # every host core this process may run on
     mt_budget = 6.0
     done = [0] * T
 
@@ -179,22 +204,40 @@ def cpu_baseline(args, tex, dim, cam, budget_s=10.0):
         th.join()
     dt_mt = time.perf_counter() - t1
     out["row_parallel"] = {"value": round(sum(done) / dt_mt / 1e6, 3), "unit": "Mrays/s", "cores": T,
-                           "sample": f"{sum(done)} rays in {dt_mt:.1f} s on {T} threads"}
+                           "sample": f"{sum(done)} rays in {dt_mt:.1f} s on {T} threads (all cores open to the process)"}
     return out
 
 
 def load_world(V, name):
     """host side of the path through the product library: .vox (or the config-4 height field) -> octree -> texel stream"""
     wld = V.World()
-    if name == "terrain":
-        import numpy as np
+    import numpy as np
+    if name == "room":   # the reference's translucent room (src/main.cpp:505-633) as its ordered insert list
+        d = np.load(os.path.join(ROOT, "tests", "golden", "room.npz"))
+        mats = json.load(open(os.path.join(ROOT, "tests", "golden", "room.json")))["materials"]
+        for (x, y, z), c, m in zip(d["xyz"], d["color"], d["material"]):
+            mm = mats[int(m)]
+            wld.insert(int(x), int(y), int(z), int(c), mm["refraction"], mm["illumination"], mm["k"])
+    elif name in ("terrain", "terrain_full"):
         tj = json.load(open(os.path.join(ROOT, "tests", "golden", "terrain.json")))
-        wd = tj["window"]
+        wd = tj["window"] if name == "terrain" else {"x0": 0, "z0": 0, "nx": 1024, "nz": 1024}
         wld.fill_heights(np.load(os.path.join(ROOT, "tests", "golden", "terrain_heights.npz"))["heights"],
                          wd["x0"], wd["z0"], wd["nx"], wd["nz"], tj["band"], tj["floor"])
     elif not wld.load_vox(os.path.join(ROOT, "tests", "golden", "maps", name + ".vox")):
         raise SystemExit("cannot load the scene fixture")
     return wld
+
+
+def upload_world(ctx, wld, name):
+    """-> (bytes of the reference's texel stream for this tree, tex_dim). The full config-4 field is beyond the stream's 2^23
+    texels: it goes up as records (vrth_world_records -> vrt_upload_records)."""
+    if name == "terrain_full":
+        rec, dim = wld.records()
+        ctx.upload_records(rec, dim)
+        return 4 * wld.texel_count(), dim
+    tex, dim = wld.flatten()
+    ctx.upload_octree(tex, dim)
+    return int(tex.size), dim
 
 
 # Untimed frames before the W warm-up steps of the headline region, to take the GPU out of its idle power state: a

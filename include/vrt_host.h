@@ -40,6 +40,10 @@ int vrth_world_find(vrth_world *w, int x, int y, int z, uint32_t out7[7]);
 /* octree_ray_cast with box (0,0,0)-(1024,1024,1024) as the reference passes (src/main.cpp:827):
  * returns 1 and the hit node's voxel coord/has_voxel, 0 on miss */
 int vrth_world_ray_cast(vrth_world *w, const float origin[3], const float dir[3], int32_t hit_coord[3], int *has_voxel);
+/* the same for n rays from one origin (dirs: n x 3 floats), one octree_ray_cast each, in order: BASELINE config 1's frame loop
+ * without a foreign-function call per pixel. hit[i] (optional) = 0 miss, 1 a node holding a voxel, 2 a node without one;
+ * hit_coords (optional) n x 3. Returns the number of rays that returned a node, or -1. */
+long vrth_world_ray_cast_many(vrth_world *w, const float origin[3], const float *dirs, size_t n, uint8_t *hit, int32_t *hit_coords);
 
 size_t vrth_world_texel_count(vrth_world *w); /* _octree_texel_size */
 /* updateGPUTexture's host half (src/main.cpp:264-271): texel stream + tex_dim.

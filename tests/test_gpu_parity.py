@@ -140,7 +140,9 @@ def test_full_size_frames_match_committed_hashes(ctx, V, golden, product_scenes,
     assert "%016x" % V.fnv1a64(rgba) == g["rgba_fnv1a64"], key
     assert "%016x" % V.fnv1a64(idd) == g["id_dist_fnv1a64"], key
     hits = int(np.count_nonzero(idd[..., 0]))
-    assert hits <= g["hits"] and hits >= g["hits"] - 4  # voxelID 0 is also a legal id for the voxel at the origin
+    # voxelID 0 is also a legal id for the voxel at the origin; a translucent first hit (the room's glass and jelly) counts as a
+    # hit but leaves the id to the first OPAQUE surface behind it, if any (comp:539-544)
+    assert hits <= g["hits"] and (g["map"] == "room" or hits >= g["hits"] - 4)
     if "shown_fnv1a64" in g:   # the frame the reference puts on screen: the display pass over the two images, three routes
         import importlib
         shd = importlib.import_module("voxel-raytracer_amd.sharding")

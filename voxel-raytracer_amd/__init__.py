@@ -81,6 +81,8 @@ def host_lib():
         L.vrth_world_find.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
         L.vrth_world_ray_cast.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                           C.POINTER(C.c_int32), C.POINTER(C.c_int)]
+        L.vrth_world_ray_cast_many.restype = C.c_long
+        L.vrth_world_ray_cast_many.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.vrth_world_texel_count.restype = C.c_size_t
         L.vrth_world_texel_count.argtypes = [C.c_void_p]
         L.vrth_world_flatten.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
@@ -290,6 +292,16 @@ class World:
         has = C.c_int(0)
         r = host_lib().vrth_world_ray_cast(self._h, o, d, hit, C.byref(has))
         return (tuple(hit), bool(has.value)) if r == 1 else None
+
+    def ray_cast_many(self, origin, dirs):
+        """octree_ray_cast for every direction of dirs[n, 3] from one origin -> (hit uint8[n]: 0 miss / 1 voxel / 2 node, coords int32[n, 3])"""
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        hit = np.zeros(d.shape[0], np.uint8)
+        coords = np.zeros((d.shape[0], 3), np.int32)
+        if host_lib().vrth_world_ray_cast_many(self._h, (C.c_float * 3)(*origin), d.ctypes.data, d.shape[0], hit.ctypes.data,
+                                               coords.ctypes.data) < 0:
+            raise VrtError("vrth_world_ray_cast_many failed")
+        return hit, coords
 
     def texel_count(self):
         return host_lib().vrth_world_texel_count(self._h)

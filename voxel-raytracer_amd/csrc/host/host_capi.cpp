@@ -107,6 +107,20 @@ int vrth_world_ray_cast(vrth_world *w, const float origin[3], const float dir[3]
     return 1;
 }
 
+long vrth_world_ray_cast_many(vrth_world *w, const float origin[3], const float *dirs, size_t n, uint8_t *hit, int32_t *hit_coords) {
+    if (!w || !origin || !dirs) return -1;
+    long hits = 0;
+    for (size_t i = 0; i < n; ++i) {
+        int32_t c[3] = {0, 0, 0};
+        int has = 0;
+        const int r = vrth_world_ray_cast(w, origin, dirs + 3 * i, c, &has);
+        if (hit) hit[i] = (uint8_t)(r == 1 ? (has ? 1 : 2) : 0);
+        if (hit_coords) { hit_coords[3 * i] = c[0]; hit_coords[3 * i + 1] = c[1]; hit_coords[3 * i + 2] = c[2]; }
+        hits += r == 1;
+    }
+    return hits;
+}
+
 size_t vrth_world_texel_count(vrth_world *w) { return w ? _octree_texel_size(w->root) : 0; }
 
 int vrth_world_flatten(vrth_world *w, uint8_t **texels, size_t *bytes, uint32_t *tex_dim) {
