@@ -300,10 +300,19 @@ int vrt_set_tile_scheduling(vrt_ctx *ctx, int period);
  *                          reference's [-1023,1024)^3 world), rays that leave it end there and the deepest node that still holds
  *                          everything stands in for the root; 2: the same without the tighter root; 0: off (rays walk the empty octants).
  *   VRT_OPT_DISPLAY_KERNEL 0 (default): the display pass sums two pixels per lane; 1: one pixel per lane (round 1's kernel; exists in
- *                          `make AB=1` builds only, VRT_E_INVALID otherwise). */
+ *                          `make AB=1` builds only, VRT_E_INVALID otherwise).
+ *   VRT_OPT_FULL_OPAQUE    VRT_MODE_FULL where pathTrace cannot branch: in a scene without translucent voxels seen from empty space it is
+ *                          the primary ray, a shadow ray and ONE diffuse bounce ray that spawns nothing (comp:573-616), so the 8-deep ray
+ *                          stack is never used. 6 (default): such launches run a kernel that holds no stack -- primary + shadow stage, then
+ *                          the bounce stage in the same wave, 80 registers instead of 96 + 560 B of scratch: 0.137 against 0.172 ms on the
+ *                          1080p dragon frame; 5, 7: the same built for five / seven waves per SIMD; 1: the two stages as two kernels with
+ *                          a 20-byte seed per pixel between them (0.158 ms: the experiment the one-kernel form came from); 0: always the
+ *                          general kernel. Scenes with a translucent voxel and eyes inside a medium take the general kernel whatever the
+ *                          setting. */
 #define VRT_OPT_RAY_TABLES 1
 #define VRT_OPT_EMPTY_OCTANTS 2
 #define VRT_OPT_DISPLAY_KERNEL 3
+#define VRT_OPT_FULL_OPAQUE 4
 int vrt_set_option(vrt_ctx *ctx, int option, int value);
 
 /* The feedback scheduler's order, read and overridden. vrt_get_tile_order copies the current workgroup-group order for the shape last

@@ -484,6 +484,96 @@ def test_materials_highlight_and_translucent_fallback(ctx, V, O):
             _assert_same(idd, ref_id, f"materials pose {pose} hl {hl} mode {mode} id/dist")
 
 
+def test_full_path_tracer_without_a_stack_for_opaque_scenes(V, O, golden, product_scenes):
+    """VRT_OPT_FULL_OPAQUE: for a scene without translucent voxels seen from empty space VRT_MODE_FULL runs its two stages -- primary +
+    shadow, then the one diffuse bounce -- without the ray stack: in one kernel (values 5, 6, 7; 6 is the default) or as two kernels
+    with a 20-byte seed per pixel between them (value 1); 0 is the general kernel. Every frame must equal the oracle's -- whole
+    frames, compact row shards with ragged tile counts, the three scheduling flavours, a highlighted voxel, emissive surfaces, two
+    streams at once. Scenes with translucent voxels and eyes inside a medium take the general kernel whatever the option says
+    (and must still match)."""
+    import torch
+    c = V.Context(0)
+    c.set_option(V.OPT_FULL_OPAQUE, 1)
+    try:
+        # the general kernel (0) and the one-kernel forms (5, 6, 7: waves per SIMD it is built for)
+        for form in (0, 5, 6, 7):
+            c.set_option(V.OPT_FULL_OPAQUE, form)
+            for name, key in (("dragon", "dragon_256x144/mode2"), ("nature", "nature_200x112/mode2"), ("dragon", "dragon_default_720p/mode2"),
+                              ("room", "room_outside_256x144/mode2"), ("dragon", "dragon_1080p_full/mode2")):
+                g = golden["frames"]["frames"][key]
+                tex, dim = product_scenes[name]
+                W, H = g["width"], g["height"]
+                _setup(c, V, tex, dim, g["pose"], W, H)
+                for _ in range(3):
+                    rgba, idd = c.dispatch(W, H, 2)
+                    assert "%016x" % V.fnv1a64(rgba) == g["rgba_fnv1a64"], (form, key)
+                    assert "%016x" % V.fnv1a64(idd) == g["id_dist_fnv1a64"], (form, key)
+        c.set_option(V.OPT_FULL_OPAQUE, 1)
+        for name, key in (("dragon", "dragon_256x144/mode2"), ("monu9", "monu9_192x108/mode2"), ("nature", "nature_200x112/mode2"),
+                          ("terrain", "terrain_240x136/mode2"), ("dragon", "dragon_inside_101x67/mode2"), ("room", "room_inside_256x144/mode2"),
+                          ("dragon", "dragon_1080p_full/mode2"), ("nature", "nature_4k_full/mode2"), ("dragon", "dragon_default_720p/mode2")):
+            g = golden["frames"]["frames"][key]
+            tex, dim = product_scenes[name]
+            W, H = g["width"], g["height"]
+            _setup(c, V, tex, dim, g["pose"], W, H)
+            for _ in range(3):   # plain, measuring, ordered launches of the shape
+                rgba, idd = c.dispatch(W, H, 2)
+                assert "%016x" % V.fnv1a64(rgba) == g["rgba_fnv1a64"], key
+                assert "%016x" % V.fnv1a64(idd) == g["id_dist_fnv1a64"], key
+            if "shown_fnv1a64" in g:
+                assert "%016x" % V.fnv1a64(c.dispatch_frame(W, H, 2)[0]) == g["shown_fnv1a64"], key
+        # a highlighted voxel on the surface, and one that only a bounce ray meets
+        tex, dim = product_scenes["dragon"]
+        W, H = 160, 90
+        for hl in ((63, 45, 28), (70, 30, 30), (40, 20, 25)):
+            cam = _setup(c, V, tex, dim, (63.5, 60.5, 140.5, -90.0, -10.0), W, H, highlighted=hl)
+            ref_rgba, ref_id, _ = _oracle_frame(O, tex, dim, cam, W, H, 2, highlighted=hl)
+            rgba, idd = c.dispatch(W, H, 2)
+            _assert_same(rgba, ref_rgba, f"two-pass highlighted {hl} rgba8")
+            _assert_same(idd, ref_id, f"two-pass highlighted {hl} id/dist")
+        # emissive and opaque voxels only (two passes), then the same world with one glass voxel (one kernel): both vs the oracle
+        rng = np.random.default_rng(21)
+        w = V.World()
+        for x in range(0, 32):
+            for z in range(0, 32):
+                w.insert(x, 0, z, 0xa0a0a0ff)
+        for _ in range(300):
+            x, y, z = (int(v) for v in rng.integers(1, 30, size=3))
+            if rng.integers(0, 3) == 0:
+                w.insert(x, y, z, 0xffd2d2ff, 3.0, 1.0, 0.0)
+            else:
+                w.insert(x, y, z, 0x50b43cff if y & 1 else 0x644628ff, 2.0 if x & 1 else 3.0, 0.0, 0.3)
+        for glass in (False, True):
+            if glass:
+                w.insert(15, 6, 15, 0xc8dcff50, 1.5, 0.0, 0.0)
+            tex, dim = w.flatten()
+            for pose in ((16.3, 22.2, 60.7, -90.0, -20.0), (2.5, 9.5, 2.5, 45.0, -10.0), (16.0, 10.0, 16.0, 0.0, 0.0)):
+                cam = _setup(c, V, tex, dim, pose, 96, 64)
+                ref_rgba, ref_id, _ = _oracle_frame(O, tex, dim, cam, 96, 64, 2)
+                rgba, idd = c.dispatch(96, 64, 2)
+                _assert_same(rgba, ref_rgba, f"two-pass emissive world glass={glass} pose {pose} rgba8")
+                _assert_same(idd, ref_id, f"two-pass emissive world glass={glass} pose {pose} id/dist")
+        # compact row shards with ragged tile counts, on two streams at once
+        tex, dim = product_scenes["monu9"]
+        W, H = 203, 117
+        cam = _setup(c, V, tex, dim, (48.5, 60.5, 170.5, -90.0, -12.0), W, H)
+        ref_rgba, ref_id, _ = _oracle_frame(O, tex, dim, cam, W, H, 2)
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for n_shards in (2, 3):
+            bufs = []
+            for s_ in range(n_shards):
+                rows = V.shard_rows(H, 5, s_, n_shards)
+                bufs.append((torch.zeros(rows * W, dtype=torch.int32, device="cuda"), torch.zeros(rows * W * 2, dtype=torch.int32, device="cuda")))
+                c.dispatch_shard(W, H, 5, s_, n_shards, 2, bufs[-1][0].data_ptr(), bufs[-1][1].data_ptr(), streams[s_ & 1].cuda_stream)
+            torch.cuda.synchronize()
+            for s_ in range(n_shards):
+                rows = V.shard_row_indices(H, 5, s_, n_shards)
+                assert np.array_equal(bufs[s_][0].cpu().numpy().view(np.uint8).reshape(-1, W, 4), ref_rgba[rows]), (n_shards, s_)
+                assert np.array_equal(bufs[s_][1].cpu().numpy().reshape(-1, W, 2), ref_id[rows]), (n_shards, s_)
+    finally:
+        c.close()
+
+
 def test_full_path_tracer_as_two_kernels(ctx, V, O, golden, product_scenes):
     """VRT_MODE_FULL runs as trace_kernel<3> + bounce_kernel (deferred diffuse bounces marched by persistent waves whose
     lanes are refilled from queues): every frame must equal the one-kernel form's and the oracle's -- whole frames, row

@@ -52,9 +52,16 @@ SUFFIX = re.compile(r"_(e32|e64|sdwa|dpp)$")
 
 
 def load_table(path, w):
+    """SIMD ticks per instruction at w resident waves (tools/micro/valu_rate: measured on SIMDs that verifiably held w waves);
+    where no SIMD qualified at that w, the largest w that has a figure."""
     t = json.load(open(path))
-    return {k: v[w].get("wall", v[w]["simd"]) for k, v in t.items()}   # by the launch wall time: the per-wave stamps
-    # over-state the rate once the probe's own registers keep fewer than w waves resident
+    out = {}
+    for k, v in t.items():
+        for ww in [w] + sorted(v, key=lambda x: -int(x[1:])):
+            if v.get(ww, {}).get("simd", 0) > 0:
+                out[k] = v[ww]["simd"]
+                break
+    return out
 
 
 def price(mn, table):
@@ -76,7 +83,7 @@ def price(mn, table):
         cls = "valu-full" if c < 3.2 else ("valu-half" if c < 6.0 else "valu-quarter")
         return c, cls
     if base.startswith("v_"):
-        return (4.4, "valu-half?") if mn.endswith("_e64") or re.search(r"3_|_or_|_add_|lshl", base) else (2.6, "valu-full?")
+        return (4.2, "valu-half?") if mn.endswith("_e64") or re.search(r"3_|_or_|_add_|lshl", base) else (2.3, "valu-full?")
     return 0.0, "other"
 
 
@@ -84,7 +91,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("asm")
     ap.add_argument("kernel")
-    ap.add_argument("--table", default=os.path.join(ROOT, "profiles", "r02_valu_rate.json"))
+    ap.add_argument("--table", default=os.path.join(ROOT, "profiles", "r03_valu_rate.json"))
     ap.add_argument("--w", default="w8")
     ap.add_argument("--blocks", action="store_true", help="per basic block lines")
     ap.add_argument("--top", type=int, default=0, help="the N most expensive mnemonics of the whole kernel")

@@ -24,7 +24,7 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
-    W, H, steps = 1920, 1080, 40
+    W, H, steps = 1920, 1080, int(os.environ.get("VRT_REHEARSAL_STEPS", "40"))
     w = V.World()
     assert w.load_vox(os.path.join(ROOT, "tests/golden/maps/dragon.vox"))
     tex, dim = w.flatten()

@@ -17,10 +17,10 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-HIP_LIB = os.path.join(HERE, "libvrt_hip.so")
+HIP_LIB = os.environ.get("VRT_HIP_LIB") or os.path.join(HERE, "libvrt_hip.so")   # VRT_HIP_LIB: an A/B build of the same library (tools)
 HOST_LIB = os.path.join(HERE, "libvrt_host.so")
 TEST_LIB = os.path.join(HERE, "libvrt_hip_test.so")   # test support, not product (csrc/test/vrt_test.hip)
-OPT_RAY_TABLES, OPT_EMPTY_OCTANTS, OPT_DISPLAY_KERNEL = 1, 2, 3
+OPT_RAY_TABLES, OPT_EMPTY_OCTANTS, OPT_DISPLAY_KERNEL, OPT_FULL_OPAQUE = 1, 2, 3, 4
 
 MODE_PRIMARY, MODE_PRIMARY_SHADOW, MODE_FULL = 0, 1, 2
 MODES = {"primary": MODE_PRIMARY, "primary_shadow": MODE_PRIMARY_SHADOW, "full": MODE_FULL}

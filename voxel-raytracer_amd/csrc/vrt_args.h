@@ -93,6 +93,7 @@ struct KArgs {
     uint32_t *defer_count;
     uint32_t defer_cap;
 };
+constexpr uint32_t kSeedPlanesHost = 5;  // words per pixel of the two-pass full path tracer's seed (vrt_common.hip.h kSeedPlanes)
 constexpr uint32_t kDeferQueues = 64;   // a wave appends to queue (tile % 64): sixty-four counters share the atomic traffic
 constexpr uint32_t kDeferStride = 64;   // words between two counters: 256 bytes
 constexpr uint32_t kDeferPlanes = 19;   // o[3] d[3] tint[3] fc[3] iof weight mc[3] md out_offset

@@ -209,10 +209,20 @@ VRT_DEV F3 primary_ray_dir(const KArgs &a, const View &vw, int px, int py) {
 template <class T, class = void> struct host_light { static constexpr bool value = false; };
 template <class T> struct host_light<T, decltype((void)T::kHostLight)> { static constexpr bool value = T::kHostLight; };
 
+// The seed pass 1 of the two-pass full path tracer (trace_kernel MODE 4) leaves per pixel for pass 2 (MODE 5, vrt_full.hip.h
+// bounce_pixel): five words, tile-major planes of 64 lanes -- seed[(tile * 5 + plane) * 64 + lane] -- so a wave's store of a plane is
+// one 256-byte line. Planes 0-2: the hit point (floats); plane 4: the bounce ray's index of refraction (float); plane 3:
+//   [23:0] the surface colour's three bytes (the hit voxel's, or the previous voxel's where comp:505-507 takes that one)
+//   [25:24] axis and [26] sign (1 = negative) of the shading normal after the flip of comp:524  [27] colour inverted (highlighted voxel)
+//   [28] the shadow ray's answer (lit)  [31] valid: this pixel has a diffuse bounce to march (an opaque, non-emissive first hit)
+constexpr uint32_t kSeedPlanes = 5, kSeedValid = 1u << 31;
+struct Seed { F3 hp; uint32_t word; float iof; };   // the same in registers (MODE 6: both passes in one wave, nothing through memory)
+
 // One pixel: ray generation (comp:624-641), primary-ray pathTrace, packing of the two outputs.
-// TRAV supplies the traversal: march(), shadow(). MODE: 0 primary, 1 primary + shadow ray.
+// TRAV supplies the traversal: march(), shadow(). MODE: 0 primary, 1 primary + shadow ray. seed (MODE 1 only): see above.
 template <int MODE, class TRAV>
-VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, int px, int py, uint32_t &rgba, int2 &idd, LateOut &lo) {
+VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, int px, int py, uint32_t &rgba, int2 &idd, LateOut &lo,
+                         uint32_t *seed = nullptr, Seed *seed_regs = nullptr) {
     const float kPI = 3.14159265359f;
     const F3 ray_dir = primary_ray_dir(a, vw, px, py);
     F3 ray_origin{vw.cam_pos[0], vw.cam_pos[1], vw.cam_pos[2]};
@@ -231,6 +241,8 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
     const float sky[3] = {0.5f, 0.7f, 1.0f};
 
     Hit h;
+    uint32_t seed_word = 0u;
+    float seed_iof = 1.0f;
     // byte form of start_iof for traversals that test media on bytes: r(b) in (0, 3) <=> 1 <= b <= 254, else 1.0 == r(85)
     const uint32_t eye_b = vw.eye1 & 0xffu;
     const uint32_t iof_byte = (eye_b >= 1u && eye_b <= 254u) ? eye_b : 85u;
@@ -290,24 +302,28 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
         Decoded hv = decode_leaf(h.h0, h.h1);
         if (hv.c[3] <= 0.0f) { hv.p[0] = 1.0f; hv.p[1] = 0.0f; hv.p[2] = 0.0f; }
         float sc[4] = {hv.c[0], hv.c[1], hv.c[2], hv.c[3]};
+        uint32_t sc_bytes = h.h0 & 0x00ffffffu;
         // surfaceColor = hitVoxel.color.a > 0 ? hitVoxel.color : lastVoxel.color (comp:505-507): the previous voxel is
         // decoded only in waves where some lane hit a voxel of alpha 0 (a phantom leaf); of its fields only the colour is
         // read on this path
         if (__builtin_amdgcn_ballot_w64((h.h0 >> 24) == 0u) != 0ull) {
             const Decoded lv = decode_leaf(h.p0, h.p1);
-            if (!(hv.c[3] > 0.0f)) { sc[0] = lv.c[0]; sc[1] = lv.c[1]; sc[2] = lv.c[2]; sc[3] = lv.c[3]; }
+            if (!(hv.c[3] > 0.0f)) { sc[0] = lv.c[0]; sc[1] = lv.c[1]; sc[2] = lv.c[2]; sc[3] = lv.c[3]; sc_bytes = h.p0 & 0x00ffffffu; }
         }
         if (dist_in_medium > 1e-6f && medium_density > 0.0f) {  // comp:512-516
             float kk = -medium_density * dist_in_medium;
 #pragma unroll
             for (int k = 0; k < 3; ++k) tc[k] = tc[k] * det_expf(kk * (1.0f - mc[k]));
         }
+        bool inverted = false;
         if (h.map.x == hl_(0) && h.map.y == hl_(1) && h.map.z == hl_(2)) {
             sc[0] = 1.0f - sc[0]; sc[1] = 1.0f - sc[1]; sc[2] = 1.0f - sc[2]; sc[3] = 1.0f;
+            inverted = true;
         }
         // dot products with an axis normal: (a*0 + b*n) + c*0 == b*n up to the sign of a zero, which neither
         // the comparisons nor the final rgba8 rounding can see (comp:522-524,537)
         float cosi = comp(ray_dir, naxis) * nval;
+        const bool flipped = cosi > 0.0f;
         if (cosi > 0.0f) nval = -nval;
         F3 normal{naxis == 0 ? nval : 0.0f, naxis == 1 ? nval : 0.0f, naxis == 2 ? nval : 0.0f};
         const F3 light = light_();
@@ -336,6 +352,15 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
                 int lit = 1;
                 if constexpr (MODE == 1 && host_light<TRAV>::value) lit = TRAV::shadow(a, tc_, add3(h.point, scale3(normal, 2e-3f)), l_ls, h);
                 else if constexpr (MODE == 1) lit = TRAV::shadow(a, tc_, add3(h.point, scale3(normal, 2e-3f)), light, h);
+                if constexpr (MODE == 1) {   // the diffuse bounce of comp:596-616 starts from here: what pass 2 needs of this hit
+                    seed_word = kSeedValid | sc_bytes | ((uint32_t)naxis << 24) | (nval < 0.0f ? 1u << 26 : 0u) | (inverted ? 1u << 27 : 0u) |
+                                (lit ? 1u << 28 : 0u);
+                    // the bounce ray travels in the medium on this side of the surface: n1 of comp:519-524 (the previous voxel's index
+                    // where it has one, else 1.0; the hit voxel's when the normal was flipped)
+                    const float prev_r = (h.p0 >> 24) != 0u ? refraction_of(h.p1) : 0.0f;
+                    const float n1 = prev_r > 0.0f ? prev_r : 1.0f, n2 = hv.p[0] > 0.0f ? hv.p[0] : 1.0f;
+                    seed_iof = flipped ? n2 : n1;
+                }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     float direct = gl[k] * (float)lit * ndotl;
@@ -347,12 +372,25 @@ VRT_DEV void trace_pixel(const KArgs &a, const View &vw, const typename TRAV::Ct
     }
     rgba = unorm8(fc[0]) | (unorm8(fc[1]) << 8) | (unorm8(fc[2]) << 16) | (255u << 24);
     idd = make_int2(voxel_id, pixel_dist);
+    if constexpr (MODE == 1) {
+        if (seed_regs) { seed_regs->hp = h.point; seed_regs->word = seed_word; seed_regs->iof = seed_iof; }
+        if (seed) {   // wave-uniform; every in-range pixel writes its word so that pass 2 never reads a stale one
+            seed[3 * 64] = seed_word;
+            if (seed_word) {
+                seed[0] = __float_as_uint(h.point.x); seed[64] = __float_as_uint(h.point.y); seed[2 * 64] = __float_as_uint(h.point.z);
+                seed[4 * 64] = __float_as_uint(seed_iof);
+            }
+        }
+    }
 }
 
 namespace full {  // MODE 2 and 3 (3: the last diffuse bounce of a pixel goes to a queue for bounce_kernel), defined in vrt_full.hip.h
 template <class TRAV, bool DEFER>
 __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename TRAV::Ctx &tc_, int px, int py, uint32_t &rgba, int2 &idd, LateOut &lo,
                                  uint32_t queue, uint32_t out_offset);
+// pass 2 of the two-pass form: the diffuse bounce of a seeded pixel; false when the pixel has none (rgba untouched)
+template <class TRAV>
+__device__ bool bounce_pixel(const KArgs &a, const typename TRAV::Ctx &tc_, int px, int py, Seed seed, uint32_t &rgba);
 }
 
 // One lane per pixel; a wave covers a TW x TH pixel tile (TW*TH == 64) so the 64 rays of a wave stay spatially
@@ -410,14 +448,40 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
             const View &vw = vs.v[blockIdx.y];
             LateOut lo;  // MODE 1, 2, 3: the output side of the arguments, re-read after the trace rather than kept in registers across it
             lo.skip_rgba = false;
-            if constexpr (MODE >= 2)
+            if constexpr (MODE == 5) {   // pass 2 of the two-pass full path tracer: only the colour of seeded pixels is (re)written
+                const uint32_t *sp = reinterpret_cast<const uint32_t *>(a.defer_rec) + ((size_t)tile * kSeedPlanes) * 64 + lane;
+                Seed seed;
+                seed.word = sp[3 * 64];
+                seed.hp = F3{0.0f, 0.0f, 0.0f};
+                seed.iof = 1.0f;
+                if (seed.word & kSeedValid) {
+                    seed.hp = F3{__uint_as_float(sp[0]), __uint_as_float(sp[64]), __uint_as_float(sp[2 * 64])};
+                    seed.iof = __uint_as_float(sp[4 * 64]);
+                }
+                if (full::bounce_pixel<TRAV>(a, tc_, px, py, seed, rgba)) {
+                    const LateArgs la = late_args();
+                    const LateView lv_ = late_view();
+                    lv_->out_rgba[(size_t)(la->compact ? j : py) * (size_t)la->width + (size_t)px] = rgba;
+                }
+            } else {
+            if constexpr (MODE == 2 || MODE == 3)
                 full::trace_pixel_full<TRAV, MODE == 3>(a, vw, tc_, px, py, rgba, idd, lo, (uint32_t)tile % kDeferQueues,
                                                         (uint32_t)((a.compact ? j : py) * a.width + px));
+            else if constexpr (MODE == 4)   // pass 1: the primary + shadow kernel, leaving a seed per pixel
+                trace_pixel<1, TRAV>(a, vw, tc_, px, py, rgba, idd, lo, reinterpret_cast<uint32_t *>(a.defer_rec) + ((size_t)tile * kSeedPlanes) * 64 + lane);
+            else if constexpr (MODE == 6) {   // both passes in this wave: the seed stays in registers
+                Seed seed;
+                seed.word = 0u;
+                trace_pixel<1, TRAV>(a, vw, tc_, px, py, rgba, idd, lo, nullptr, &seed);
+                uint32_t both;
+                if (full::bounce_pixel<TRAV>(a, tc_, px, py, seed, both)) rgba = both;
+            }
             else trace_pixel<MODE, TRAV>(a, vw, tc_, px, py, rgba, idd, lo);
             if constexpr (MODE == 0) lo = LateOut{vw.out_rgba, vw.out_id, a.width, a.compact, false};
             size_t o = (size_t)(lo.compact ? j : py) * (size_t)lo.width + (size_t)px;
             if (lo.out_rgba && !lo.skip_rgba) lo.out_rgba[o] = rgba;
             if (lo.out_id) lo.out_id[o] = idd;
+            }
         }
         if constexpr (SCHED & 2) {  // the wave has reconverged: this is the time its slowest ray took
             if (lane == 0) a.tile_cost[tile] = (uint32_t)(__builtin_readcyclecounter() - t_begin);

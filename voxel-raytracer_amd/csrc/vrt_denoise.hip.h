@@ -145,14 +145,37 @@ __device__ __forceinline__ int slot(const int col) {
     return (col % PX) * (kSpanX / PX) + col / PX;
 }
 
-#ifndef VRT_DENOISE_MASKED_TAP   // a 0/1 mask multiplied in: compare, select, two packed fmas
+#ifndef VRT_DENOISE_TAP
+#define VRT_DENOISE_TAP 0
+#endif
+#ifndef VRT_DENOISE_MASKED_TAP   // a 0/1 mask multiplied in: compare, select, then the four sums
+// How the four sums are issued (same values in every form: an fma with a 0/1 multiplier IS the conditional add, and count + m is
+// fma(m, 1, count)). A gfx950 SIMD issues one vector instruction per ~2.3 cycles whatever its kind and runs the half-rate kinds
+// (v_cmp, v_cndmask, every v_pk_*_f32) on a second pipe that needs ~4.3 cycles for each (profiles/r03_valu_rate.txt), so a tap
+// costs max(2.3 x instructions, 4.3 x half-rate instructions):
+//   0  v_cmp, v_cndmask, 2 x v_pk_fma_f32                      (round 1-2)   4 instructions, 4 half-rate: 17.2
+//   1  v_cmp, v_cndmask, v_pk_fma_f32 (r, g), v_fma_f32 (b), v_add_f32 (count)  5 instructions, 3 half-rate: 12.9
+//   2  v_cmp, v_cndmask, 3 x v_fma_f32, v_add_f32                           6 instructions, 2 half-rate: 13.8
 __device__ __forceinline__ void tap(const f4 rec, const int cid, f2 &rg, f2 &bc, const bool in_range = true) {
     const float m = (__float_as_int(rec.w) == cid && in_range) ? 1.0f : 0.0f;
+#if VRT_DENOISE_TAP == 0
     const f2 mm = {m, m};
     const f2 c01 = {rec.x, rec.y};
     const f2 c2 = {rec.z, 1.0f};
     rg = __builtin_elementwise_fma(mm, c01, rg);
     bc = __builtin_elementwise_fma(mm, c2, bc);
+#elif VRT_DENOISE_TAP == 1
+    const f2 mm = {m, m};
+    const f2 c01 = {rec.x, rec.y};
+    rg = __builtin_elementwise_fma(mm, c01, rg);
+    bc.x = __builtin_fmaf(m, rec.z, bc.x);
+    bc.y = bc.y + m;
+#else
+    rg.x = __builtin_fmaf(m, rec.x, rg.x);
+    rg.y = __builtin_fmaf(m, rec.y, rg.y);
+    bc.x = __builtin_fmaf(m, rec.z, bc.x);
+    bc.y = bc.y + m;
+#endif
 }
 #else
 // Tried in round 2 and measured SLOWER (kept for the record, -DVRT_DENOISE_MASKED_TAP): the conditional add as what it

@@ -126,6 +126,32 @@ vrt_ctx::RayTable *ray_table(vrt_ctx *c, const float *inv_proj, int W, int H) {
 }
 
 // views == nullptr: one view, the context's camera (vrt_set_camera) rendering into d_rgba / d_id.
+// True when pathTrace cannot take its translucent branch (comp:546-572) or absorb (comp:482-486, 512-516) anywhere in this tree for
+// an eye in empty space: every leaf has alpha 0 (never a hit: its medium byte reads as empty space) or alpha 255 with a refraction
+// byte that makes it a surface (not 0 and not 85, which the hit test cannot tell from empty space).
+static bool tree_is_opaque(const std::vector<vrt::Record> &rec) {
+    if (rec.empty()) return false;
+    std::vector<uint32_t> todo{0u};
+    while (!todo.empty()) {
+        const uint32_t i = todo.back();
+        todo.pop_back();
+        const uint32_t mask = rec[i].w0 & 0xffu, leaf_mask = (rec[i].w0 >> 8) & 0xffu;
+        uint32_t child = rec[i].w1;
+        for (uint32_t ci = 0; ci < 8; ++ci) {
+            if (!((mask >> ci) & 1u)) continue;
+            if ((size_t)child >= rec.size()) return false;
+            if ((leaf_mask >> ci) & 1u) {
+                const uint32_t alpha = rec[child].w0 >> 24, refr = rec[child].w1 & 0xffu;
+                if (alpha != 0u && (alpha != 255u || refr == 0u || refr == 85u)) return false;
+            } else {
+                todo.push_back(child);
+            }
+            ++child;
+        }
+    }
+    return true;
+}
+
 int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_rows, int row_stride, int compact,
             int mode, void *d_rgba, void *d_id, hipStream_t s, const vrt_view *views, int n_views) {
     if (!c->have_scene) return fail(c, VRT_E_STATE, "vrt_dispatch: no octree uploaded (call vrt_upload_octree first)");
@@ -334,6 +360,43 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
         a.defer_count = dq->count;
         a.defer_cap = (uint32_t)dq->cap;
     }
+    // the full path tracer as two tile-coherent passes, where the scene and the view allow it
+    bool two_pass = false;
+    if (mode == VRT_MODE_FULL && c->two_pass_on && v.trav == 4 && n_views == 1 && c->variant == 0 && !split && vs.v[0].out_rgba) {
+        if (!c->scene_opaque_valid) { c->scene_opaque = tree_is_opaque(c->host_records); c->scene_opaque_valid = true; }
+        const uint32_t eye_alpha = vs.v[0].eye0 >> 24, eye_b = vs.v[0].eye1 & 0xffu;
+        two_pass = c->scene_opaque && eye_alpha == 0u && (eye_b == 0u || eye_b == 85u || eye_b == 255u);
+    }
+    if (two_pass && c->two_pass_form >= 5) {
+        e = vrt::launch::trace_full_opaque(a, vs, (int)grid, c->two_pass_form, s, ev0, ev1);
+    } else if (two_pass) {
+        vrt_ctx::SeedBuffer *sb = nullptr;
+        for (auto &b : c->seeds)
+            if (b.stream == s) sb = &b;
+        if (!sb) {
+            if (c->seeds.size() < 8) {
+                c->seeds.emplace_back();
+                sb = &c->seeds.back();
+            } else {
+                for (auto &b : c->seeds)
+                    if (!sb || b.last_use < sb->last_use) sb = &b;
+                VRT_HIP(c, hipStreamSynchronize(sb->stream));   // its launches may still be in flight there
+            }
+            sb->stream = s;
+        }
+        const size_t need = (size_t)(a.group_order ? groups * vrt::kGroupTiles : tiles);
+        if (need > sb->tiles) {
+            VRT_HIP(c, hipStreamSynchronize(s));
+            uint32_t *fresh = nullptr;
+            VRT_HIP(c, hipMalloc((void **)&fresh, need * vrt::kSeedPlanesHost * 64 * sizeof(uint32_t)));
+            if (sb->d) (void)hipFree(sb->d);
+            sb->d = fresh;
+            sb->tiles = need;
+        }
+        sb->last_use = ++c->seed_tick;
+        a.defer_rec = reinterpret_cast<float *>(sb->d);
+        e = vrt::launch::trace_full_two_pass(a, vs, (int)grid, s, ev0, ev1);
+    } else
 #if VRT_AB
     if (split) e = vrt::launch::trace_split(a, vs, (int)grid, c->n_cus * 4 * c->bounce_waves_per_simd, c->bounce_refill_below, s, ev0, ev1);
     else
@@ -565,6 +628,11 @@ int vrt_set_option(vrt_ctx *c, int option, int value) {
             if (value < 0 || value > 2) break;
             c->root0_only_on = value != 0;
             c->tight_root_on = value == 1;   // 2: the shortcut with wide root 0 as build_wide() found it
+            return VRT_OK;
+        case VRT_OPT_FULL_OPAQUE:
+            if (value != 0 && value != 1 && (value < 5 || value > 7)) break;
+            c->two_pass_on = value != 0;
+            c->two_pass_form = value;   // 1: two kernels and a seed buffer; 5, 6, 7: both stages in one kernel at that many waves per SIMD
             return VRT_OK;
         case VRT_OPT_DISPLAY_KERNEL:
             if (value == 0 || (value == 1 && VRT_AB)) { c->denoise_variant = value; return VRT_OK; }

@@ -347,5 +347,89 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
     lo.skip_rgba = deferred;
 }
 
+// ---- the two-pass form for opaque scenes ------------------------------------------------------------------------------------
+// In a scene without translucent voxels seen from empty space, pathTrace (comp:435-622) is: the primary ray; on an opaque,
+// non-emissive hit a shadow ray and ONE diffuse bounce ray, which spawns nothing (comp:590-594). Pass 1 (trace_kernel MODE 4) is the
+// primary + shadow kernel -- 64 VGPRs, seven waves per SIMD, no ray stack -- leaving a 20-byte seed per pixel; pass 2 (MODE 5,
+// this function) marches the bounce rays of the seeded pixels in the same 8 x 8 tiles (the coherence the one-kernel form has),
+// again without a stack, and writes the pixel's final colour. The accumulation order per pixel is pathTrace's: direct term, then
+// the bounce's term. Everything pass 2 recomputes is computed from the same inputs by the same operations as pass 1 did.
+template <class TRAV>
+__device__ bool bounce_pixel(const KArgs &a, const typename TRAV::Ctx &tc_, int px, int py, const Seed seed, uint32_t &rgba) {
+    const uint32_t word = seed.word;
+    const bool valid = (word & kSeedValid) != 0u;
+    if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return false;   // a tile without bounces (sky, emissive surfaces)
+    if (!valid) return false;
+    const float kPI = 3.14159265359f;
+    const float sky[3] = {0.5f, 0.7f, 1.0f};
+    const float kSun = 3.0f;
+    const F3 hp = seed.hp;
+    const float n1 = seed.iof;
+    const bool shade_fast = a.shade_fast != 0;
+    const auto over_pi = [&](float x) { return shade_fast ? div_pi_inrange(x) : x / kPI; };
+    // the surface colour and the normal as pass 1 used them
+    float sc[3] = {unorm_of((float)(word & 0xffu)), unorm_of((float)((word >> 8) & 0xffu)), unorm_of((float)((word >> 16) & 0xffu))};
+    if (word & (1u << 27)) { sc[0] = 1.0f - sc[0]; sc[1] = 1.0f - sc[1]; sc[2] = 1.0f - sc[2]; }
+    const int naxis = (int)((word >> 24) & 3u);
+    const float nval = (word & (1u << 26)) ? -1.0f : 1.0f;
+    const F3 normal{naxis == 0 ? nval : 0.0f, naxis == 1 ? nval : 0.0f, naxis == 2 ? nval : 0.0f};
+    const float *gl = a.global_light;
+    const F3 light{a.light_dir[0], a.light_dir[1], a.light_dir[2]};
+    const float ndotl = fmax_c(nval * comp(light, naxis), 0.0f);
+    const float lit = (word & (1u << 28)) ? 1.0f : 0.0f;
+    float fc[3], tint[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {   // comp:587-589 as trace_pixel<1> evaluates it (the throughput of a primary ray from empty space is the light)
+        const float direct = gl[k] * lit * ndotl;
+        fc[k] = 0.0f + over_pi(direct * sc[k] * gl[k] * 1.0f);
+        tint[k] = gl[k] * sc[k];
+    }
+    // comp:596-616: the first two random numbers of the pixel
+    uint32_t rng = rng_init(px, py, 0);
+    const float rx = rng_next(rng), ry = rng_next(rng);
+    const F3 bd = cosine_hemisphere(normal, rx, ry);
+    const F3 ro = add3(hp, scale3(normal, 1e-1f));
+    Hit h;
+    // A bounce ray starts in the medium in front of the surface: empty space (n1 = 1.0), which the one-loop march of views from
+    // empty space (TRAV::Eye85) takes -- except behind a flipped normal (an axis-aligned ray on a zero direction component, comp:497,
+    // 524: n1 is then the hit voxel's index). A wave that holds such a lane marches all its rays with the general loop.
+    bool hit;
+    if (__builtin_amdgcn_ballot_w64(n1 != 1.0f) == 0ull) hit = TRAV::Eye85::march(a, tc_, ro, bd, 1.0f, 85u, h);
+    else hit = TRAV::General::march(a, tc_, ro, bd, n1, iof_to_byte(n1), h);
+    if (!hit) {   // depth 1 (comp:489-495)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) fc[k] = fc[k] + over_pi(tint[k] * sky[k] * kSun * 1.0f);
+    } else {
+        F3 hpw = h.point;
+        float dim;
+        if (a.voxel_scale != 1.0f) {
+            hpw = F3{h.point.x / a.voxel_scale, h.point.y / a.voxel_scale, h.point.z / a.voxel_scale};
+            dim = 0.0f + len3(sub3(hpw, ro)) / a.voxel_scale;
+        } else {
+            dim = 0.0f + len3(sub3(hpw, ro));
+        }
+        Decoded hv = decode_leaf(h.h0, h.h1);
+        const Decoded last = decode_leaf(h.p0, h.p1);
+        if (hv.c[3] <= 0.0f) { hv.p[1] = 0.0f; }
+        float s2[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s2[k] = hv.c[3] > 0.0f ? hv.c[k] : last.c[k];
+        if (h.map.x == a.highlighted[0] && h.map.y == a.highlighted[1] && h.map.z == a.highlighted[2]) {
+            s2[0] = 1.0f - s2[0]; s2[1] = 1.0f - s2[1]; s2[2] = 1.0f - s2[2];
+        }
+        const float emission = hv.p[1] * 10.0f;
+        if (emission > 0.0f) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) fc[k] = fc[k] + over_pi(tint[k] * s2[k] * emission * 1.0f);
+        } else {
+            const float amb = fmax_c(1.0f - det_expf(-dim / 512.0f), 0.01f);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) fc[k] = fc[k] + over_pi(amb * s2[k] * tint[k] * 1.0f);
+        }
+    }
+    rgba = unorm8(fc[0]) | (unorm8(fc[1]) << 8) | (unorm8(fc[2]) << 16) | (255u << 24);
+    return true;
+}
+
 }  // namespace full
 }  // namespace vrt

@@ -175,6 +175,14 @@ struct vrt_ctx {
     };
     std::vector<RayTable> ray_tables;
     uint64_t ray_tick = 0;
+    // VRT_MODE_FULL as two passes (vrt_launch.h trace_full_two_pass): the option, what the uploaded tree allows, the seed buffers
+    bool two_pass_on = true;                     // vrt_set_option(VRT_OPT_FULL_OPAQUE)
+    int two_pass_form = 6;                       // 6 (default): both stages in one kernel built for six waves per SIMD; 5, 7: for five, seven; 1: two kernels
+    bool scene_opaque = false;                   // every leaf has alpha 0, or alpha 255 and a refraction byte that is a surface (not 0 / 85)
+    bool scene_opaque_valid = false;
+    struct SeedBuffer { hipStream_t stream = nullptr; uint32_t *d = nullptr; size_t tiles = 0; uint64_t last_use = 0; };
+    std::vector<SeedBuffer> seeds;               // one per stream: launches on different streams may overlap
+    uint64_t seed_tick = 0;
     bool tight_root_on = true;                   // vrt_debug_set_root0_only(2 = on without the tighter root)
     bool root0_only_on = true;                   // vrt_debug_set_root0_only(0): never tell the kernels that the world is empty outside wide root 0
     bool ray_tables_on = true;                   // vrt_debug_set_ray_tables(0): always the shader's own prologue (A/B, tests)

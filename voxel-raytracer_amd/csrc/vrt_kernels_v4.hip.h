@@ -72,6 +72,8 @@ template <bool EYE85>
 struct TravT {
     static constexpr bool kStagesLds = false;
     using Ctx = v3::Trav::Ctx;
+    using Eye85 = TravT<true>;   // the same traversal with the one march loop of rays that start in empty space
+    using General = TravT<false>;   // ... and with the loop that takes a ray's own starting medium
 
     template <int BLOCK>
     static VRT_DEV void block_init(const KArgs &a, uint2 *, Ctx &c) { c.root = a.nodes[0]; }

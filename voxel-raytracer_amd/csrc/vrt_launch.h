@@ -12,6 +12,12 @@ namespace launch {
 hipError_t trace_primary(const Variant &v, const KArgs &a, const ViewSet &vs, int grid, size_t lds, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 hipError_t trace_shadow(const Variant &v, const KArgs &a, const ViewSet &vs, int grid, size_t lds, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 hipError_t trace_full(const Variant &v, const KArgs &a, const ViewSet &vs, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+// The full path tracer as two tile-coherent passes (vrt_full.hip.h bounce_pixel) for scenes the dispatcher has checked: pass 1 = the
+// primary + shadow kernel leaving a seed per pixel in a.defer_rec, pass 2 = the diffuse bounce of the seeded pixels. ev0 rides on
+// pass 1, ev1 on pass 2 (their elapsed time spans both).
+// ... and the same two stages in ONE kernel, the seed in registers (no stack, no seed traffic, no second launch); wpe 5, 6 or 7
+hipError_t trace_full_opaque(const KArgs &a, const ViewSet &vs, int grid, int wpe, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+hipError_t trace_full_two_pass(const KArgs &a, const ViewSet &vs, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 inline hipError_t trace(int mode, const Variant &v, const KArgs &a, const ViewSet &vs, int grid, size_t lds, hipStream_t s, hipEvent_t ev0,
                         hipEvent_t ev1) {
     return mode == VRT_MODE_FULL ? trace_full(v, a, vs, grid, s, ev0, ev1)

@@ -14,5 +14,20 @@ hipError_t trace_full(const Variant &v, const KArgs &a, const ViewSet &vs, int g
     if (v.trav == 2) return launch_one<2, v2::Trav<false>, 8, 256, 1>(a, vs, grid, 0, s);
     return launch_one<2, v1::Trav<false>, 8, 256, 1>(a, vs, grid, 0, s);
 }
+
+hipError_t trace_full_opaque(const KArgs &a, const ViewSet &vs, int grid, int wpe, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    if (wpe == 7) return launch_sched<6, v4::Trav, 8, 64, 7>(a, vs, grid, 0, s, ev0, ev1);
+    if (wpe == 5) return launch_sched<6, v4::Trav, 8, 64, 5>(a, vs, grid, 0, s, ev0, ev1);
+    return launch_sched<6, v4::Trav, 8, 64, 6>(a, vs, grid, 0, s, ev0, ev1);
+}
+
+hipError_t trace_full_two_pass(const KArgs &a, const ViewSet &vs, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    hipError_t e = launch_sched<4, v4::Trav, 8, 64, 7>(a, vs, grid, 0, s, ev0, nullptr);
+    if (e != hipSuccess) return e;
+    KArgs b = a;            // pass 2 starts its tiles in the same order; the tile times that are measured are pass 1's
+    b.tile_cost = nullptr;
+    return launch_sched<5, v4::TravAny, 8, 64, 7>(b, vs, grid, 0, s, nullptr, ev1);
+}
+
 }  // namespace launch
 }  // namespace vrt

@@ -40,6 +40,7 @@ int patch_host(vrt_ctx *c, const vrt_patch &patch, const uint32_t *subtree_recor
     if (!vrt::apply_patch(c->host_records, c->wide, wide_now, site, reinterpret_cast<const vrt::Record *>(subtree_records), n_records, rg, why))
         return fail(c, VRT_E_MALFORMED, "vrt_patch_apply: " + why);   // apply_patch modifies nothing when it refuses
     bt.dirty = true;
+    c->scene_opaque_valid = false;   // the tree changed: what the two-pass path tracer may assume about it is re-derived
     bt.rewritten_records.push_back(site.record);
     bt.texel_delta += rg.texel_delta;
     if (wide_now) {
@@ -174,6 +175,7 @@ int vrt_compact(vrt_ctx *c) {
     VRT_HIP(c, hipSetDevice(c->device));
     VRT_HIP(c, hipDeviceSynchronize());   // dispatches in flight read the old arrays
     vrt::compact_records(c->host_records);
+    c->scene_opaque_valid = false;
     struct Guard { vrt_ctx *c; bool armed = true; ~Guard() { if (armed) { c->have_scene = false; c->analysis_valid = false; } } } guard{c};
     const size_t bytes = c->host_records.size() * sizeof(vrt::Record);
     if (bytes > c->nodes_capacity) {   // cannot grow, but a context whose array was never sized stays correct

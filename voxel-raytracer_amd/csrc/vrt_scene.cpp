@@ -201,6 +201,8 @@ void vrt_destroy(vrt_ctx *c) {
         (void)hipFree(d.rec);
         (void)hipFree(d.count);
     }
+    if (!c->seeds.empty()) (void)hipDeviceSynchronize();   // their launches may be on the caller's streams
+    for (auto &b : c->seeds) (void)hipFree(b.d);
     if (!c->sched.empty()) (void)hipDeviceSynchronize();  // their launches may be on the caller's streams
     for (SchedState &st : c->sched) {
         (void)hipFree(st.d_cost);
@@ -272,6 +274,7 @@ int vrt_upload_octree(vrt_ctx *c, const uint8_t *texels, size_t used_bytes, uint
     c->stream_texels = used_bytes / 4;
     c->dim_from_texels = tex_dim == dim_of_texels(c->stream_texels);
     c->analysis_valid = false;
+    c->scene_opaque_valid = false;
     c->have_scene = true;
     return VRT_OK;
 }
@@ -336,6 +339,7 @@ int vrt_upload_records(vrt_ctx *c, const uint32_t *records, size_t n_records, ui
     c->stream_texels = vrt::stream_texels(c->host_records.data(), c->host_records.size(), 0);
     c->dim_from_texels = tex_dim == dim_of_texels(c->stream_texels);
     c->analysis_valid = false;
+    c->scene_opaque_valid = false;
     c->have_scene = true;
     return VRT_OK;
 }
