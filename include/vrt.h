@@ -98,6 +98,11 @@ typedef struct vrt_patch {
     uint8_t path[16];    /* child index taken at levels 0 .. depth-1 */
 } vrt_patch;
 int vrt_patch_plan(vrt_ctx *ctx, int x, int y, int z, int max_depth, vrt_patch *out);
+/* The same for an edit that touched a whole BOX of voxels [lo, hi] (inclusive) -- a fill, an explosion: the deepest patchable
+ * ancestor whose cube holds the box. The host library then emits ONE sub-tree for it (vrth_octree_box_records: only the nodes
+ * that meet the box are walked, the rest are "keep" records) and ONE vrt_patch_apply replaces it: a 16^3 fill is one patch,
+ * not 4,096. */
+int vrt_patch_plan_box(vrt_ctx *ctx, const int32_t lo[3], const int32_t hi[3], int max_depth, vrt_patch *out);
 int vrt_patch_apply(vrt_ctx *ctx, const vrt_patch *patch, const uint32_t *subtree_records, size_t n_records);
 /* A batch of edits (a brush stroke, an explosion; src/main.cpp:843-914 re-flattens once per click): between
  * vrt_patch_begin and vrt_patch_end, vrt_patch_plan / vrt_patch_apply work on the library's host copy of the structures

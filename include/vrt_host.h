@@ -67,6 +67,11 @@ int vrth_octree_path_records(void *octree_root, const uint8_t *path, int depth, 
                              size_t *n_records);
 int vrth_world_path_records(vrth_world *w, const uint8_t *path, int depth, int x, int y, int z, uint32_t **records,
                             size_t *n_records);
+/* ... and for an edit of a whole box of voxels [lo, hi] (inclusive) under the node vrt_patch_plan_box names: the nodes that meet the box */
+int vrth_octree_box_records(void *octree_root, const uint8_t *path, int depth, const int32_t lo[3], const int32_t hi[3], uint32_t **records,
+                            size_t *n_records);
+int vrth_world_box_records(vrth_world *w, const uint8_t *path, int depth, const int32_t lo[3], const int32_t hi[3], uint32_t **records,
+                           size_t *n_records);
 int vrth_world_node_state(vrth_world *w, const uint8_t *path, int depth);
 int vrth_world_subtree_records(vrth_world *w, const uint8_t *path, int depth, uint32_t **records, size_t *n_records);
 void vrth_free(void *p);

@@ -1259,6 +1259,67 @@ def test_views_in_one_launch_equal_separate_dispatches(ctx, V, product_scenes):
         ctx.dispatch_views(W, H, 8, 0, 1, 0, [cams[0] + (0, 0)] * 5)
 
 
+def test_box_edits_are_one_patch_and_equal_full_uploads(V, O):
+    """vrt_patch_plan_box + vrth_world_box_records: a fill or a clearance of a whole box of voxels is ONE sub-tree patch (the
+    reference re-flattens and re-uploads the world on every click, src/main.cpp:843-914). Aligned and unaligned boxes, boxes that
+    cross the 64-unit anchors of the wide layout, boxes in empty space, boxes carved out of the model, a box of glass (the full
+    path tracer then leaves its stack-free form); after every edit the patched context renders what a context with a full upload
+    of the edited tree renders, and what the oracle renders."""
+    rng = np.random.default_rng(5)
+    w = V.World()
+    assert w.load_vox(os.path.join(MAPS, "dragon.vox"))
+    a, b = V.Context(0), V.Context(0)
+    try:
+        a.upload_octree(*w.flatten())
+        W, H = 160, 90
+        cams = [V.camera_block(p[:3], p[3], p[4], W, H)[:3] for p in ((63.5, 60.5, 140.5, -90.0, -10.0), (30.5, 70.5, 20.5, 45.0, -35.0))]
+        boxes = [((64, 40, 16), 16, "fill", 0x3296c8ff, 3.0), ((50, 30, 20), 16, "clear", 0, 0.0), ((57, 59, 27), 16, "fill", 0xc86432ff, 3.0),
+                 ((10, 80, 40), 4, "fill", 0xffd2d2ff, 3.0), ((120, 2, 50), 9, "fill", 0x50b43cff, 3.0), ((60, 20, 20), 7, "clear", 0, 0.0),
+                 ((200, 200, 200), 16, "fill", 0xa0a0a0ff, 3.0), ((40, 60, 10), 5, "fill", 0xc8dcff50, 1.5), ((0, 0, 0), 32, "clear", 0, 0.0)]
+        patched = 0
+        for k, (lo, n, what, colour, refr) in enumerate(boxes):
+            hi = tuple(v + n - 1 for v in lo)
+            g = (np.indices((n, n, n)).reshape(3, -1).T + np.array(lo)).astype(np.int32)
+            if what == "fill":
+                keep = rng.random(len(g)) < (1.0 if k % 2 == 0 else 0.7)    # solid boxes merge into few leaves; ragged ones do not
+                w.insert_many(g[keep], np.full(int(keep.sum()), colour, np.uint32), refr, 1.0 if colour == 0xffd2d2ff else 0.0, 0.0)
+            else:
+                for x, y, z in g:
+                    w.remove(int(x), int(y), int(z))
+            before = a.scene_info()["n_records"]
+            depth = a.patch_box(w, lo, hi)
+            if depth is None:
+                a.upload_octree(*w.flatten())
+            else:
+                patched += 1
+            tex, dim = w.flatten()
+            b.upload_octree(tex, dim)
+            info = a.scene_info()
+            assert (info["n_texels"], info["tex_dim"]) == (len(tex) // 4, dim), (k, info, len(tex) // 4, dim)
+            assert depth is None or info["n_records"] - before < 40000, (k, depth, info["n_records"] - before)
+            for ci, cam in enumerate(cams):
+                for variant, modes in ((0, (0, 1, 2)), (20, (1,)), (4, (1,))):
+                    for mode in modes:
+                        frames = []
+                        for ctx_ in (a, b):
+                            ctx_.set_variant(variant)
+                            ctx_.set_camera(*cam)
+                            frames.append(ctx_.dispatch(W, H, mode))
+                        what_ = f"box {k} {what} {lo}+{n} pose {ci} variant {variant} mode {mode}"
+                        _assert_same(frames[0][0], frames[1][0], what_ + " rgba8 (patched vs full upload)")
+                        _assert_same(frames[0][1], frames[1][1], what_ + " id/dist (patched vs full upload)")
+                        if variant == 0 and mode == 2:
+                            ref_rgba, ref_id, _ = _oracle_frame(O, tex, dim, cam, W, H, mode)
+                            _assert_same(frames[0][0], ref_rgba, what_ + " rgba8 vs oracle")
+                            _assert_same(frames[0][1], ref_id, what_ + " id/dist vs oracle")
+        assert patched >= 7, patched
+        with pytest.raises(V.VrtError):
+            a._chk(a._L.vrt_patch_plan_box(a._h, (__import__("ctypes").c_int32 * 3)(5, 5, 5), (__import__("ctypes").c_int32 * 3)(4, 9, 9), 15, __import__("ctypes").byref(V.Patch())))
+    finally:
+        a.close()
+        b.close()
+
+
 def test_voxel_edits_patched_on_device_equal_full_uploads(V, O):
     """vrt_patch_plan / vrt_patch_apply: after every build / destroy edit of the host octree, the context patched in
     place renders the frames of a context that received a full upload of the edited tree (wide, bit-indexed and

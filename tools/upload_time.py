@@ -69,6 +69,44 @@ def main():
         b = time.perf_counter()
         print("%-8s %d edits patched: median %7.3f ms each (sub-tree depth %s); flatten + upload + layout %7.1f ms"
               % (name, len(ts), float(np.median(ts)) * 1e3 if ts else -1.0, sorted(set(depths)), (b - a) * 1e3))
+        # box edits: a fill of n^3 voxels as ONE patch (vrt_patch_plan_box / vrth_world_box_records) against n^3 single-voxel
+        # patches in a batch and against the reference's route (re-flatten + upload on every click, src/main.cpp:843-914)
+        for n in (4, 16):
+            one, many = [], []
+            for trial in range(6):
+                lo = [int(v) for v in rng.integers(2, 90, size=3)]
+                if trial % 2 == 0:
+                    lo = [v & ~(n - 1) for v in lo]          # aligned: the box is one octree node's worth
+                hi = [v + n - 1 for v in lo]
+                g = np.indices((n, n, n)).reshape(3, -1).T + np.array(lo)
+                col = np.full(len(g), 0x3296c8ff if trial & 1 else 0xc86432ff, np.uint32)
+                w.insert_many(g.astype(np.int32), col)
+                a = time.perf_counter()
+                d = ctx.patch_box(w, lo, hi)
+                b = time.perf_counter()
+                if d is not None:
+                    one.append((b - a, d))
+                # the same fill elsewhere as n^3 voxel patches in one batch
+                lo2 = [v + 100 for v in lo]
+                g2 = g + 100
+                a = time.perf_counter()
+                ctx.patch_begin()
+                ok = True
+                for (x, y, z), c_ in zip(g2, col):   # a voxel patch describes ONE edit: insert, patch, insert, patch ...
+                    w.insert(int(x), int(y), int(z), int(c_))
+                    ok = ok and ctx.patch_voxel(w, int(x), int(y), int(z)) is not None
+                    if not ok:
+                        break
+                ctx.patch_end()
+                b = time.perf_counter()
+                if ok:
+                    many.append(b - a)
+                else:
+                    t3, d3 = w.flatten()
+                    ctx.upload_octree(t3, d3)
+            print("%-8s %2d^3 fill: one box patch median %7.3f ms (depths %s), %d voxel patches in a batch median %8.3f ms"
+                  % (name, n, float(np.median([t for t, _ in one])) * 1e3 if one else -1.0, sorted({d for _, d in one}), n ** 3,
+                     float(np.median(many)) * 1e3 if many else -1.0))
 
 
 if __name__ == "__main__":

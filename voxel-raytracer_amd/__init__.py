@@ -643,6 +643,32 @@ class Context:
             max_depth = plan.depth - 1
         return None
 
+    def patch_box(self, world, lo, hi, max_depth=15):
+        """After `world` has been edited anywhere inside the box of voxels [lo, hi] (inclusive): ONE patch for the whole box
+        (vrt_patch_plan_box / vrth_world_box_records / vrt_patch_apply). Returns the depth of the node replaced, or None when the
+        edit needs a full upload."""
+        H = host_lib()
+        H.vrth_world_node_state.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int]
+        H.vrth_world_box_records.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        self._L.vrt_patch_plan_box.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.POINTER(Patch)]
+        lo3, hi3 = (C.c_int32 * 3)(*[int(v) for v in lo]), (C.c_int32 * 3)(*[int(v) for v in hi])
+        plan = Patch()
+        while max_depth >= 1:
+            if self._L.vrt_patch_plan_box(self._h, lo3, hi3, max_depth, C.byref(plan)) != 0:
+                return None
+            if H.vrth_world_node_state(world._h, plan.path, plan.depth) == 2:
+                p, n = C.c_void_p(), C.c_size_t(0)
+                if H.vrth_world_box_records(world._h, plan.path, plan.depth, lo3, hi3, C.byref(p), C.byref(n)) != 0:
+                    return None
+                try:
+                    self._chk(self._L.vrt_patch_apply(self._h, C.byref(plan), p, n.value))
+                finally:
+                    H.vrth_free(p)
+                return plan.depth
+            max_depth = plan.depth - 1
+        return None
+
     def patch_begin(self):
         self._chk(self._L.vrt_patch_begin(self._h))
 

@@ -152,9 +152,10 @@ inline bool counted(const Octree *c) { return c && (c->has_voxel || c->children)
 
 // Records of the sub-tree under `top` in level order, top = record 0 (child indices local to the sub-tree);
 // `top_depth` = depth of `top` below the root, for the 16-iteration truncation of the shader's descent.
-// toward != NULL: only children whose box holds that voxel are expanded; every other internal child becomes a
-// "keep" record {0xffffffff, 0xffffffff} (the child and everything below it is as it was: vrt_patch_apply shares it).
-void emit_records(const Octree *top, uint32_t top_depth, std::vector<uint32_t> &out, const int *toward = nullptr) {
+// box != NULL ({lo x, y, z, hi x, y, z}, inclusive voxel coordinates: the region an edit touched): only children whose cube
+// meets that box are expanded; every other internal child becomes a "keep" record {0xffffffff, 0xffffffff} (the child and
+// everything below it is as it was: vrt_patch_apply shares it).
+void emit_records(const Octree *top, uint32_t top_depth, std::vector<uint32_t> &out, const int *box = nullptr) {
     struct Item { const Octree *n; uint32_t rec, depth; };
     out.assign(2, 0u);
     std::vector<Item> queue;
@@ -180,9 +181,9 @@ void emit_records(const Octree *top, uint32_t top_depth, std::vector<uint32_t> &
                 out.push_back(w0);
                 out.push_back(w1);
                 leaf_mask |= 1u << i;
-            } else if (toward && !(toward[0] >= c->left_bot_back.x && toward[0] < c->right_top_front.x &&
-                                   toward[1] >= c->left_bot_back.y && toward[1] < c->right_top_front.y &&
-                                   toward[2] >= c->left_bot_back.z && toward[2] < c->right_top_front.z)) {
+            } else if (box && !(box[3] >= c->left_bot_back.x && box[0] < c->right_top_front.x &&
+                                box[4] >= c->left_bot_back.y && box[1] < c->right_top_front.y &&
+                                box[5] >= c->left_bot_back.z && box[2] < c->right_top_front.z)) {
                 out.push_back(0xffffffffu);
                 out.push_back(0xffffffffu);
             } else {
@@ -254,10 +255,28 @@ int vrth_octree_path_records(void *octree_root, const uint8_t *path, int depth, 
     if (!octree_root || (!path && depth > 0) || depth < 0 || depth > 15 || !records || !n_records) return -1;
     const Octree *n = walk(static_cast<const Octree *>(octree_root), path, depth);
     if (!n || !n->children) return -2;
-    const int toward[3] = {x, y, z};
+    const int box[6] = {x, y, z, x, y, z};
     std::vector<uint32_t> out;
-    emit_records(n, (uint32_t)depth, out, toward);
+    emit_records(n, (uint32_t)depth, out, box);
     return hand_over(out, records, n_records);
+}
+
+// ... and for an edit of a whole box of voxels [lo, hi] (inclusive): one sub-tree, the nodes that meet the box walked and emitted
+int vrth_octree_box_records(void *octree_root, const uint8_t *path, int depth, const int32_t lo[3], const int32_t hi[3], uint32_t **records,
+                            size_t *n_records) {
+    if (!octree_root || (!path && depth > 0) || depth < 0 || depth > 15 || !records || !n_records || !lo || !hi) return -1;
+    const Octree *n = walk(static_cast<const Octree *>(octree_root), path, depth);
+    if (!n || !n->children) return -2;
+    const int box[6] = {lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]};
+    if (box[0] > box[3] || box[1] > box[4] || box[2] > box[5]) return -1;
+    std::vector<uint32_t> out;
+    emit_records(n, (uint32_t)depth, out, box);
+    return hand_over(out, records, n_records);
+}
+
+int vrth_world_box_records(vrth_world *w, const uint8_t *path, int depth, const int32_t lo[3], const int32_t hi[3], uint32_t **records,
+                           size_t *n_records) {
+    return w ? vrth_octree_box_records(w->root, path, depth, lo, hi, records, n_records) : -1;
 }
 
 int vrth_world_path_records(vrth_world *w, const uint8_t *path, int depth, int x, int y, int z, uint32_t **records,

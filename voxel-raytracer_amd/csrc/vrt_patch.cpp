@@ -103,8 +103,9 @@ int patch_device(vrt_ctx *c) {
 
 extern "C" {
 
-int vrt_patch_plan(vrt_ctx *c, int x, int y, int z, int max_depth, vrt_patch *out) {
-    if (!c || !out) return c ? fail(c, VRT_E_INVALID, "vrt_patch_plan: null output") : VRT_E_INVALID;
+int vrt_patch_plan_box(vrt_ctx *c, const int32_t lo[3], const int32_t hi[3], int max_depth, vrt_patch *out) {
+    if (!c || !out || !lo || !hi) return c ? fail(c, VRT_E_INVALID, "vrt_patch_plan: null argument") : VRT_E_INVALID;
+    if (lo[0] > hi[0] || lo[1] > hi[1] || lo[2] > hi[2]) return fail(c, VRT_E_INVALID, "vrt_patch_plan_box: lo > hi");
     if (!c->have_scene) return fail(c, VRT_E_STATE, "vrt_patch_plan: no octree uploaded");
     VRT_HIP(c, hipSetDevice(c->device));
     int r = ensure_analysis(c);
@@ -116,14 +117,33 @@ int vrt_patch_plan(vrt_ctx *c, int x, int y, int z, int max_depth, vrt_patch *ou
         if (!r) r = ensure_analysis(c);
         if (r) return r;
     }
-    vrt::PatchSite site;
-    const int p[3] = {x, y, z};
-    if (!vrt::plan_patch(c->host_records, c->wide, c->wide_ok && !c->batch.wide_invalid, c->params.world_min, c->params.world_max, p,
-                         max_depth > 15 ? 15 : max_depth, site))
-        return fail(c, VRT_E_STATE, "vrt_patch_plan: no patchable ancestor (full upload needed)");
-    out->depth = site.depth;
-    std::memcpy(out->path, site.path, sizeof out->path);
-    return VRT_OK;
+    // the deepest patchable ancestor of the box's first voxel whose cube also holds its last one
+    const int p[3] = {lo[0], lo[1], lo[2]};
+    int md = max_depth > 15 ? 15 : max_depth;
+    while (md >= 1) {
+        vrt::PatchSite site;
+        if (!vrt::plan_patch(c->host_records, c->wide, c->wide_ok && !c->batch.wide_invalid, c->params.world_min, c->params.world_max, p, md, site))
+            break;
+        int mn[3], mx[3];
+        for (int k = 0; k < 3; ++k) { mn[k] = c->params.world_min[k]; mx[k] = c->params.world_max[k]; }
+        for (int d = 0; d < site.depth; ++d)
+            for (int k = 0; k < 3; ++k) {
+                const int mid = mn[k] + ((mx[k] - mn[k]) >> 1);
+                if ((site.path[d] >> (2 - k)) & 1u) mn[k] = mid; else mx[k] = mid;
+            }
+        if (hi[0] < mx[0] && hi[1] < mx[1] && hi[2] < mx[2] && hi[0] >= mn[0] && hi[1] >= mn[1] && hi[2] >= mn[2]) {
+            out->depth = site.depth;
+            std::memcpy(out->path, site.path, sizeof out->path);
+            return VRT_OK;
+        }
+        md = site.depth - 1;
+    }
+    return fail(c, VRT_E_STATE, "vrt_patch_plan: no patchable ancestor (full upload needed)");
+}
+
+int vrt_patch_plan(vrt_ctx *c, int x, int y, int z, int max_depth, vrt_patch *out) {
+    const int32_t p[3] = {x, y, z};
+    return vrt_patch_plan_box(c, p, p, max_depth, out);
 }
 
 int vrt_patch_begin(vrt_ctx *c) {
