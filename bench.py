@@ -270,8 +270,9 @@ def lib_stamp(V):
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "voxel-raytracer_amd", "csrc")
-    for f in sorted(os.listdir(csrc)):
-        if f.endswith((".hip.h", ".hip")) or f in ("vrt_args.h", "vrt_layout.h", "vrt_layout.cpp", "vrt_dispatch.cpp"):
+    for f in sorted(os.listdir(csrc)):   # what shapes the TRACE kernels and their launches (not the display pass, not the multi-GPU code)
+        if (f.startswith(("vrt_kernels", "vrt_launch_")) and f != "vrt_launch_misc.hip") or f in (
+                "vrt_common.hip.h", "vrt_full.hip.h", "vrt_args.h", "vrt_layout.h", "vrt_layout.cpp", "vrt_dispatch.cpp"):
             h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -27,8 +27,12 @@ def main():
     ctx = V.Context(0)
     bad = frames = hits = 0
     t0 = time.time()
+    opaque_only = [0, 1, 2, 5, 6]    # materials a world may hold and still run the stack-free full path tracer (alpha 255 or 0)
     for case in range(n):
         w = V.World()
+        # every other world holds no translucent voxel: VRT_MODE_FULL then takes the kernel without a ray stack (VRT_OPT_FULL_OPAQUE)
+        # unless the eye sits inside a voxel
+        palette = [PALETTE[i] for i in opaque_only] if case % 2 == 0 else PALETTE
         span = int(rng.choice([12, 40, 200]))
         positive = rng.random() < 0.6            # content in the octant [0, 1024)^3 only
         lo = 0 if positive else -span // 4
@@ -38,7 +42,7 @@ def main():
             y = int(rng.integers(0, span // 2 + 1))
             x0, z0 = (int(v) for v in rng.integers(lo, span // 2, size=2))
             sx, sz = (int(v) for v in rng.integers(2, 14, size=2))
-            m = PALETTE[int(rng.integers(0, len(PALETTE)))]
+            m = palette[int(rng.integers(0, len(palette)))]
             xs, zs = np.meshgrid(np.arange(x0, x0 + sx), np.arange(z0, z0 + sz))
             xyz = np.stack([xs.ravel(), np.full(xs.size, y), zs.ravel()], axis=1) + base
             w.insert_many(xyz.astype(np.int32), np.full(len(xyz), m[0], np.uint32), m[1], m[2], m[3])
@@ -50,7 +54,7 @@ def main():
             if positive:
                 xyz = np.abs(xyz)
             xyz = xyz + base
-            m = PALETTE[int(rng.integers(0, len(PALETTE)))]
+            m = palette[int(rng.integers(0, len(palette)))]
             w.insert_many(xyz.astype(np.int32), np.full(k, m[0], np.uint32), m[1], m[2], m[3])
             pts.append(xyz)
         pts = np.concatenate(pts)
@@ -89,6 +93,10 @@ def main():
                     ld[int(rng.integers(0, 3))] = 0.0
                 p.light_dir[:] = [float(v) for v in ld]
                 s.light_dir[:] = [float(v) for v in ld]
+            if rng.random() < 0.3:
+                hv = pts[int(rng.integers(0, len(pts)))]
+                p.highlighted[:] = [int(v) for v in hv]
+                s.highlighted[:] = [int(v) for v in hv]
             if rng.random() < 0.3:
                 vs = float(np.float32(rng.choice([0.5, 2.0, 1.25])))
                 p.voxel_scale = vs

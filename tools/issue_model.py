@@ -93,10 +93,11 @@ def probe_constants():
 
 
 def half_share(mode):
-    """static share of half/quarter-rate kinds among the vector instructions inside the loops of the shipped kernel of `mode`"""
-    src = {"primary": "vrt_launch_primary.hip", "primary_shadow": "vrt_launch_shadow.hip", "full": "vrt_launch_full.hip"}[mode]
+    """static share of half/quarter-rate kinds among the vector instructions inside the loops of the kernel a workload of `mode` ran
+    (mode "full_opaque": the stack-free full path tracer, trace_kernel<6, ...>)"""
+    src = {"primary": "vrt_launch_primary.hip", "primary_shadow": "vrt_launch_shadow.hip", "full": "vrt_launch_full.hip", "full_opaque": "vrt_launch_full.hip"}[mode]
     sym = {"primary": "trace_kernelILi0ENS_2v45TravTILb1EEELi8ELi64ELi7ELb0ELi1EEE", "primary_shadow": "trace_kernelILi1ENS_2v45TravTILb1EEELi8ELi64ELi7ELb0ELi1EEE",
-           "full": "trace_kernelILi2ENS_2v45TravTILb0EEELi8ELi64ELi5ELb0ELi1EEE"}[mode]
+           "full": "trace_kernelILi2ENS_2v45TravTILb0EEELi8ELi64ELi5ELb0ELi1EEE", "full_opaque": "trace_kernelILi6ENS_2v45TravTILb1EEELi8ELi64ELi6ELb0ELi1EEE"}[mode]
     csrc = os.path.join(ROOT, "voxel-raytracer_amd", "csrc")
     asm = f"/tmp/issue_model_{mode}.s"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
@@ -138,12 +139,15 @@ def build(summary_path):
             continue
         c = kernels[pick]["counters"]
         d = kernels[pick]["dispatch_ns_by_pass"]
-        if mode not in shares:
-            shares[mode] = half_share(mode)
+        kmode = mode
+        if mode == "full" and "trace_kernel<6" in pick:
+            kmode = "full_opaque"
+        if kmode not in shares:
+            shares[kmode] = half_share(kmode)
         key = f"{mp}/{W}x{H}/{mode}/variant0"
         e = {"kernel": pick, "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "salu_insts_per_launch": c.get("SQ_INSTS_SALU"),
              "waves": c.get("SQ_WAVES"), "trans_insts": c.get("SQ_INSTS_VALU_TRANS_F32"), "cvt_insts": c.get("SQ_INSTS_VALU_CVT"),
-             "half_rate_share": shares[mode][0], "half_rate_share_from": {"static loop blocks": shares[mode][1]}}
+             "half_rate_share": shares[kmode][0], "half_rate_share_from": {"static loop blocks": shares[kmode][1]}}
         # the kernel's own cycles: SQ_BUSY_CYCLES (cycles with waves present, summed over the shader engines); its duration in the
         # same pass gives the clock it ran at under the collection
         ns0 = d.get("pass0") or d.get("pass0_trace")
@@ -153,7 +157,7 @@ def build(summary_path):
             e["frac_under_pmc"] = round(e["valu_insts_per_launch"] * consts["issue_slot_cycles"] / 1024 / busy, 4)
             e["frac_at_2_cycles_under_pmc"] = round(e["valu_insts_per_launch"] * 2.0 / 1024 / busy, 4)
             e["scalar_port_frac_under_pmc"] = round((e["salu_insts_per_launch"] or 0) * consts["salu_cycles"] / 1024 / busy, 4)
-            e["half_pipe_frac_under_pmc"] = round(e["valu_insts_per_launch"] * shares[mode][0] * consts["half_pipe_cycles"] / 1024 / busy, 4)
+            e["half_pipe_frac_under_pmc"] = round(e["valu_insts_per_launch"] * shares[kmode][0] * consts["half_pipe_cycles"] / 1024 / busy, 4)
             if ns0:
                 e["kernel_ms_under_pmc"] = round(ns0 * 1e-6, 5)
                 e["clock_ghz"] = round(busy / ns0, 4)

@@ -212,8 +212,10 @@ __device__ __forceinline__ void tap(const f4 rec, const int cid, f2 &rg, f2 &bc,
 // compiler hoists the row's LDS reads ahead of their use. (Cutting the row into register double-buffered chunks
 // pinned by empty asm statements was measured: 4% faster on a frame where every wave has one radius, 10-25% slower
 // on rendered frames, so the rows are left to the scheduler.)
+// y_first..y_last (wave-uniform, inside [-RM, RM]): the window rows that can hold a tap of one of the wave's ids at all (tile():
+// rows outside it add +0 to every sum and are skipped).
 template <int PX, int RM, int DELTA>
-__device__ __forceinline__ void rows_static(const f4 *row, const int (&cid)[PX], const int (&R)[PX], Acc<PX> &acc) {
+__device__ __forceinline__ void rows_static(const f4 *row, const int (&cid)[PX], const int (&R)[PX], Acc<PX> &acc, const int y_first, const int y_last) {
     constexpr int D = DELTA < RM ? DELTA : RM;
     unsigned extent[PX];
     int inner_first[PX];
@@ -222,8 +224,9 @@ __device__ __forceinline__ void rows_static(const f4 *row, const int (&cid)[PX],
         extent[k] = (unsigned)(2 * R[k]);
         inner_first[k] = RM - R[k] + k;
     }
+    row += (y_first + RM) * kStride<PX>;
 #pragma unroll 1
-    for (int y = -RM; y <= RM; ++y, row += kStride<PX>) {
+    for (int y = y_first; y <= y_last; ++y, row += kStride<PX>) {
         const bool middle = D == 0 || (D < RM && y >= -(RM - D) && y <= RM - D);  // wave-uniform
         if (middle) {
 #pragma unroll
@@ -256,11 +259,12 @@ __device__ __forceinline__ void rows_static(const f4 *row, const int (&cid)[PX],
 }
 
 template <int PX, int DELTA>
-__device__ __forceinline__ void rows_dispatch(const f4 *row, const int rm, const int (&cid)[PX], const int (&R)[PX], Acc<PX> &acc) {
+__device__ __forceinline__ void rows_dispatch(const f4 *row, const int rm, const int (&cid)[PX], const int (&R)[PX], Acc<PX> &acc, const int y_first,
+                                              const int y_last) {
     switch (rm) {
 #define VRT_DENOISE_CASE(r) \
     case r:                 \
-        rows_static<PX, r, DELTA>(row, cid, R, acc); \
+        rows_static<PX, r, DELTA>(row, cid, R, acc, y_first, y_last); \
         break;
         VRT_DENOISE_CASE(1) VRT_DENOISE_CASE(2) VRT_DENOISE_CASE(3) VRT_DENOISE_CASE(4) VRT_DENOISE_CASE(5)
         VRT_DENOISE_CASE(6) VRT_DENOISE_CASE(7) VRT_DENOISE_CASE(8) VRT_DENOISE_CASE(9) VRT_DENOISE_CASE(10)
@@ -272,8 +276,23 @@ __device__ __forceinline__ void rows_dispatch(const f4 *row, const int rm, const
 
 // One tile (bx, by) by one workgroup of (32 / PX) x TH lanes; s_unorm holds byte / 255.0f. Ends with every lane
 // past its last LDS read of this tile, but not synchronised.
+// Which rows of the staged window hold a given id at all. A pixel's sum only takes taps that carry its own voxelID -- the pixels of
+// ONE voxel face -- and at the distances where the radius is large a face is a dozen pixels across while the window is 41 x 41:
+// most of a window's rows hold no tap of the id, and a row without one adds +0 to every sum, which leaves it unchanged (the sums
+// are non-negative). So the tile keeps, for every id one of its OWN pixels carries, the first and last staged row that id occurs
+// in (a 128-slot open-addressing table in LDS: ids claimed with atomicCAS before staging, rows folded in with atomicMin / atomicMax
+// while staging), and a wave walks only the rows between the lowest first and the highest last row of its lanes' ids. An id the
+// table has no room for switches the tile back to whole windows. Same taps in the same order for every sum: same bits.
+constexpr int kIdSlots = 128;
+struct IdRows {
+    int id[kIdSlots];       // 0 = free (a pixel with id 0 is never summed)
+    int lo[kIdSlots], hi[kIdSlots];
+    int overflow;
+};
+__device__ __forceinline__ uint32_t id_slot(const int id) { return ((uint32_t)id * 2654435761u) >> 25; }   // 7 bits
+
 template <int PX, int TH>
-__device__ __forceinline__ void tile(const Args &a, const int bx, const int by, f4 *s_rec, const float *s_unorm) {
+__device__ __forceinline__ void tile(const Args &a, const int bx, const int by, f4 *s_rec, const float *s_unorm, IdRows *s_ids) {
     constexpr int kTH = TH, kSpanY = TH + 2 * kMaxR;
     constexpr int kLanesX = kTW / PX, kThreads = kLanesX * kTH, kTaps = kSpanX * kSpanY;
     static_assert(kSpanX % PX == 0, "column swizzle");
@@ -281,6 +300,8 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
     const int px0 = bx * kTW + threadIdx.x * PX, py = by * kTH + threadIdx.y;
     int cid[PX], R[PX];
     int r_hi = 0, r_lo = kMaxR + 1;
+    for (int i = tid; i < kIdSlots; i += kThreads) { s_ids->id[i] = 0; s_ids->lo[i] = 0x7fffffff; s_ids->hi[i] = -0x7fffffff; }
+    if (tid == 0) s_ids->overflow = 0;
 #pragma unroll
     for (int k = 0; k < PX; ++k) {
         const int px = px0 + k;
@@ -310,10 +331,30 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
         }
         return;
     }
+    // the ids of the tile's own pixels claim their slots (the barrier above ordered the table's initialisation before this)
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+        if (cid[k] == 0) continue;
+        uint32_t sl = id_slot(cid[k]);
+        int tries = 0;
+        for (; tries < kIdSlots; ++tries, sl = (sl + 1u) & (kIdSlots - 1)) {
+            const int was = atomicCAS(&s_ids->id[sl], 0, cid[k]);
+            if (was == 0 || was == cid[k]) break;
+        }
+        if (tries == kIdSlots) s_ids->overflow = 1;
+    }
+    __syncthreads();
     // stage the 72 x (TH + 40) window: loads of a whole batch are issued before the first is consumed
     const int tx0 = bx * kTW - kMaxR, ty0 = by * kTH - kMaxR;
     constexpr int kBatch = 8;
     constexpr int kStageIters = (kTaps + kThreads * kBatch - 1) / (kThreads * kBatch) * kBatch;
+    // a thread's taps mostly carry one id after another (its taps lie 3.5 rows apart in one column band): runs of one id are folded
+    // in registers and reach the table once per run -- on a close-up where one face fills the tile that is two atomics per thread
+    // instead of two per tap on ONE slot
+    int run_id = 0, run_slot = -1, run_lo = 0, run_hi = 0;
+    const auto flush_run = [&]() {
+        if (run_slot >= 0) { atomicMin(&s_ids->lo[run_slot], run_lo); atomicMax(&s_ids->hi[run_slot], run_hi); }
+    };
     for (int b = 0; b < kStageIters; b += kBatch) {
         int vid[kBatch];
         uint32_t col[kBatch];
@@ -340,8 +381,26 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
             rec.z = s_unorm[(col[j] >> 16) & 0xffu];
             rec.w = __int_as_float(vid[j]);
             if (i < kTaps) s_rec[ly * kStride<PX> + slot<PX>(lx)] = rec;
+            if (vid[j] != 0 && i < kTaps) {   // fold this tap's row into its id's range, if one of the tile's own pixels carries that id
+                if (vid[j] == run_id) {
+                    run_lo = ly < run_lo ? ly : run_lo;
+                    run_hi = ly > run_hi ? ly : run_hi;
+                } else {
+                    flush_run();
+                    run_id = vid[j];
+                    run_slot = -1;
+                    run_lo = run_hi = ly;
+                    uint32_t sl = id_slot(vid[j]);
+                    for (int tries = 0; tries < kIdSlots; ++tries, sl = (sl + 1u) & (kIdSlots - 1)) {
+                        const int at = s_ids->id[sl];
+                        if (at == vid[j]) { run_slot = (int)sl; break; }
+                        if (at == 0) break;
+                    }
+                }
+            }
         }
     }
+    flush_run();
     __syncthreads();
 
 #pragma unroll
@@ -361,13 +420,36 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
     }
     if (r_hi != 0) {  // some pixel of this wave is summed
         const int rm = r_hi, delta = r_hi - r_lo;
+        // the rows this wave has to walk: from the lowest first row to the highest last row of its lanes' ids, inside the window
+        int y_first = rm, y_last = -rm;   // relative to the lane's own row (all lanes of a wave row share threadIdx.y: window row y is staged row threadIdx.y + kMaxR + y)
+        if (s_ids->overflow) { y_first = -rm; y_last = rm; }
+        else {
+#pragma unroll
+            for (int k = 0; k < PX; ++k) {
+                if (cid[k] == 0) continue;
+                uint32_t sl = id_slot(cid[k]);
+                while (s_ids->id[sl] != cid[k]) sl = (sl + 1u) & (kIdSlots - 1);   // present: claimed above
+                const int lo = s_ids->lo[sl] - (int)(threadIdx.y + kMaxR), hi = s_ids->hi[sl] - (int)(threadIdx.y + kMaxR);
+                const int f = lo < -R[k] ? -R[k] : lo, l = hi > R[k] ? R[k] : hi;
+                y_first = f < y_first ? f : y_first;
+                y_last = l > y_last ? l : y_last;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const int f = __shfl_xor(y_first, off), l = __shfl_xor(y_last, off);
+                y_first = f < y_first ? f : y_first;
+                y_last = l > y_last ? l : y_last;
+            }
+            y_first = __builtin_amdgcn_readfirstlane(y_first);
+            y_last = __builtin_amdgcn_readfirstlane(y_last);
+        }
         const f4 *row = s_rec + (threadIdx.y + kMaxR - rm) * kStride<PX> + threadIdx.x;  // window row -rm, lane column base
         if (delta == 0)
-            rows_dispatch<PX, 0>(row, rm, cid, R, acc);
+            rows_dispatch<PX, 0>(row, rm, cid, R, acc, y_first, y_last);
         else if (delta == 1)
-            rows_dispatch<PX, 1>(row, rm, cid, R, acc);
+            rows_dispatch<PX, 1>(row, rm, cid, R, acc, y_first, y_last);
         else
-            rows_dispatch<PX, kFull>(row, rm, cid, R, acc);
+            rows_dispatch<PX, kFull>(row, rm, cid, R, acc, y_first, y_last);
     }
     if (py >= a.height) return;
 #pragma unroll
@@ -398,9 +480,10 @@ template <int PX, int TH, bool SCHED = false>
 __global__ __launch_bounds__(kTW / PX *TH) __attribute__((amdgpu_waves_per_eu(2, 2))) void denoise_px_kernel(const Args a) {
     __shared__ f4 s_rec[kStride<PX> * (TH + 2 * kMaxR)];
     __shared__ float s_unorm[256];
+    __shared__ IdRows s_ids;
     if constexpr (!SCHED) {
         fill_unorm<PX, TH>(s_unorm);
-        tile<PX, TH>(a, blockIdx.x, blockIdx.y, s_rec, s_unorm);
+        tile<PX, TH>(a, blockIdx.x, blockIdx.y, s_rec, s_unorm, &s_ids);
     } else {  // 1-D grid of whole groups; the tiles of a frame differ by two orders of magnitude (sky: a copy; radius 20: 1,681 taps)
         int t = (int)blockIdx.x;
         if (a.group_order) t = (int)a.group_order[blockIdx.x / kGroupTiles] * kGroupTiles + (int)(blockIdx.x % kGroupTiles);
@@ -408,7 +491,7 @@ __global__ __launch_bounds__(kTW / PX *TH) __attribute__((amdgpu_waves_per_eu(2,
         const unsigned long long t_begin = a.tile_cost ? __builtin_readcyclecounter() : 0ull;
         fill_unorm<PX, TH>(s_unorm);
         const int by = t / a.tiles_x;
-        tile<PX, TH>(a, t - by * a.tiles_x, by, s_rec, s_unorm);
+        tile<PX, TH>(a, t - by * a.tiles_x, by, s_rec, s_unorm, &s_ids);
         if (a.tile_cost && ((threadIdx.y * (kTW / PX) + threadIdx.x) & 63) == 0)
             atomicMax(&a.tile_cost[t], (uint32_t)(__builtin_readcyclecounter() - t_begin));
     }
