@@ -27,6 +27,18 @@ struct RayS {            // comp:57-68 without the fields nothing reads (defined
     int depth;
 };
 
+// What waits on the stack: only the REFLECTED ray of a glass hit ever does (the refracted one and every diffuse bounce are marched
+// next and take the finished ray's registers), and such a ray has depth 0 and travels in the medium of the voxel before the
+// surface, so its medium colour and density are that voxel's colour word (comp:556-562: lastVoxel.color, lastVoxel.color.a * 5):
+// 13 words instead of 17 per entry.
+struct StackRay {
+    F3 o, d;
+    float iof, weight;
+    float tint[3];
+    float dim;
+    uint32_t medium;     // leaf word 0 (R | G<<8 | B<<16 | alpha<<24) of the voxel the ray travels in
+};
+
 VRT_DEV F3 cross3(F3 x, F3 y) { return F3{x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y}; }
 
 VRT_DEV float det_logf(float x) {  // x > 0, normal (Cephes logf, plain mul/add)
@@ -194,7 +206,7 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
     // The ray stack (comp:451) lives in private memory: 8 x 68 bytes per lane. (Holding the entry pushed last in registers
     // until it is popped -- no scratch traffic at all for opaque scenes -- was measured: the 17 extra live values push
     // the 96-register build into 20 spills and the frame from 0.261 to 0.282 ms.)
-    RayS stack[kMaxRays];
+    StackRay stack[kMaxRays];
     // the primary ray starts in registers, and so does a diffuse bounce pushed on an empty stack (every bounce of an opaque
     // scene): pushed and popped at once they made a store -> load round trip through scratch, 17 words each way per lane
     RayS r;
@@ -205,7 +217,23 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
     }
     int sp = 0;
     bool in_regs = true;   // `r` already holds the ray to march next: the primary ray, or a diffuse bounce pushed on an empty stack
-    const auto push = [&](const RayS &nr) { stack[sp++] = nr; };
+    const auto push = [&](const RayS &nr, uint32_t medium) {
+        StackRay e;
+        e.o = nr.o; e.d = nr.d; e.iof = nr.iof; e.weight = nr.weight;
+        e.tint[0] = nr.tint[0]; e.tint[1] = nr.tint[1]; e.tint[2] = nr.tint[2];
+        e.dim = nr.dim; e.medium = medium;
+        stack[sp++] = e;
+    };
+    const auto pop = [&]() {
+        const StackRay e = stack[--sp];
+        r.o = e.o; r.d = e.d; r.iof = e.iof; r.weight = e.weight;
+        r.tint[0] = e.tint[0]; r.tint[1] = e.tint[1]; r.tint[2] = e.tint[2];
+        r.dim = e.dim;
+        r.mc[0] = unorm_of((float)(e.medium & 0xffu)); r.mc[1] = unorm_of((float)((e.medium >> 8) & 0xffu));
+        r.mc[2] = unorm_of((float)((e.medium >> 16) & 0xffu));
+        r.md = unorm_of((float)(e.medium >> 24)) * 5.0f;
+        r.depth = 0;
+    };
     bool deferred = false;
     float fc[3] = {0.0f, 0.0f, 0.0f};
     const float *gl = a.global_light;
@@ -215,7 +243,7 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
     const auto over_pi = [&](float x) { return shade_fast ? div_pi_inrange(x) : x / kPI; };
 
     while (in_regs || sp > 0) {
-        if (!in_regs) r = stack[--sp];
+        if (!in_regs) pop();
         in_regs = false;
         Hit h;
         const bool hit = TRAV::march(a, tc_, r.o, r.d, r.iof, iof_to_byte(r.iof), h);
@@ -291,7 +319,7 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
             if (reflect_i > 0.001f && sp < kMaxRays) {
                 const float rw = r.weight * reflect_i;
                 if (rw > 1e-4f)
-                    push(make_ray(add3(hp, scale3(normal, 1e-4f)), reflect3(inc, normal), n1, rw, tc, r.dim, last.c, last.c[3] * 5.0f, r.depth));
+                    push(make_ray(add3(hp, scale3(normal, 1e-4f)), reflect3(inc, normal), n1, rw, tc, r.dim, last.c, last.c[3] * 5.0f, r.depth), h.p0);
             }
             if (refract_i > 0.001f && sp < kMaxRays && !has_tir) {
                 // the last push of this iteration, hence the next ray marched: it takes r's registers (see `in_regs`)
@@ -329,14 +357,16 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
                 const F3 bd = cosine_hemisphere(normal, rx, ry);
                 const float nw = r.weight / (float)kIndirectSamples;
                 const float tint[3] = {tc[0] * sc[0], tc[1] * sc[1], tc[2] * sc[2]};
+                static_assert(kIndirectSamples == 1, "the bounce ray takes the finished ray's registers: one per hit");
                 if (DEFER && sp == 0) {
                     defer_bounce(a, queue, out_offset, add3(hp, scale3(normal, 1e-1f)), bd, tint, fc, n1, nw, last.c, last.c[3] * 5.0f);
                     deferred = true;
-                } else if (sp == 0) {   // it would be popped at once: it takes r's registers instead of a trip through scratch
+                } else {
+                    // Pushed last, it is the ray popped next -- whatever else waits on the stack (the reflections of the glass
+                    // the primary ray came through): it takes r's registers instead of a round trip through scratch, 17 words each
+                    // way per lane with the march waiting on the reload. (Round 2 did this for an empty stack only.)
                     r = make_ray(add3(hp, scale3(normal, 1e-1f)), bd, n1, nw, tint, 0.0f, last.c, last.c[3] * 5.0f, r.depth + 1);
                     in_regs = true;
-                } else {
-                    push(make_ray(add3(hp, scale3(normal, 1e-1f)), bd, n1, nw, tint, 0.0f, last.c, last.c[3] * 5.0f, r.depth + 1));
                 }
             }
         }
