@@ -123,6 +123,7 @@ __global__ __launch_bounds__(kTile *kTile) void denoise_kernel(const Args a) {
 constexpr int kTW = 32;                  // tile width; the height TH is a kernel parameter (16 by default)
 constexpr int kSpanX = kTW + 2 * kMaxR;  // 72
 constexpr int kFull = kMaxR;             // DELTA value of the instance that range-tests every tap
+constexpr int kSeg = 4;                  // a row's taps are walked in segments of this many columns; a segment no lane needs is skipped (2, 3, 7, 10 measured slower)
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -214,8 +215,13 @@ __device__ __forceinline__ void tap(const f4 rec, const int cid, f2 &rg, f2 &bc,
 // on rendered frames, so the rows are left to the scheduler.)
 // y_first..y_last (wave-uniform, inside [-RM, RM]): the window rows that can hold a tap of one of the wave's ids at all (tile():
 // rows outside it add +0 to every sum and are skipped).
-template <int PX, int RM, int DELTA>
-__device__ __forceinline__ void rows_static(const f4 *row, const int (&cid)[PX], const int (&R)[PX], Acc<PX> &acc, const int y_first, const int y_last) {
+// SEGMENTED: a row's taps are walked in segments of kSeg columns and the segments in which no lane has a tap of its ids are skipped
+// (seg_mask, wave-uniform); the other instance is the row as ONE piece of straight-line code, for waves that need every column
+// (a close-up, one face filling the window): the segment branches keep the compiler from hoisting a whole row's LDS reads, which
+// costs such a wave 14 %.
+template <int PX, int RM, int DELTA, bool SEGMENTED>
+__device__ __forceinline__ void rows_static(const f4 *row, const int (&cid)[PX], const int (&R)[PX], Acc<PX> &acc, const int y_first, const int y_last,
+                                            const uint32_t seg_mask) {
     constexpr int D = DELTA < RM ? DELTA : RM;
     unsigned extent[PX];
     int inner_first[PX];
@@ -228,17 +234,23 @@ __device__ __forceinline__ void rows_static(const f4 *row, const int (&cid)[PX],
 #pragma unroll 1
     for (int y = y_first; y <= y_last; ++y, row += kStride<PX>) {
         const bool middle = D == 0 || (D < RM && y >= -(RM - D) && y <= RM - D);  // wave-uniform
+        constexpr int kSegW = SEGMENTED ? kSeg : 2 * RM + PX;   // unsegmented: one segment holds the row
+        constexpr int kSegs = (2 * RM + PX + kSegW - 1) / kSegW;
         if (middle) {
 #pragma unroll
-            for (int u = 0; u < 2 * RM + PX; ++u) {
-                const f4 t = row[slot<PX>(kMaxR - RM + u)];
+            for (int sg = 0; sg < kSegs; ++sg) {
+                if (SEGMENTED && !((seg_mask >> sg) & 1u)) continue;   // wave-uniform: no lane has a tap of its ids in these columns
 #pragma unroll
-                for (int k = 0; k < PX; ++k) {
-                    if (u < k || u > k + 2 * RM) continue;
-                    if (u >= k + D && u <= k + 2 * RM - D)
-                        tap(t, cid[k], acc.rg[k], acc.bc[k]);
-                    else
-                        tap(t, cid[k], acc.rg[k], acc.bc[k], (unsigned)(u - inner_first[k]) <= extent[k]);
+                for (int u = sg * kSegW; u < (sg + 1) * kSegW && u < 2 * RM + PX; ++u) {
+                    const f4 t = row[slot<PX>(kMaxR - RM + u)];
+#pragma unroll
+                    for (int k = 0; k < PX; ++k) {
+                        if (u < k || u > k + 2 * RM) continue;
+                        if (u >= k + D && u <= k + 2 * RM - D)
+                            tap(t, cid[k], acc.rg[k], acc.bc[k]);
+                        else
+                            tap(t, cid[k], acc.rg[k], acc.bc[k], (unsigned)(u - inner_first[k]) <= extent[k]);
+                    }
                 }
             }
         } else {
@@ -246,12 +258,16 @@ __device__ __forceinline__ void rows_static(const f4 *row, const int (&cid)[PX],
 #pragma unroll
             for (int k = 0; k < PX; ++k) first[k] = (y >= -R[k] && y <= R[k]) ? inner_first[k] : 4 * kMaxR;
 #pragma unroll
-            for (int u = 0; u < 2 * RM + PX; ++u) {
-                const f4 t = row[slot<PX>(kMaxR - RM + u)];
+            for (int sg = 0; sg < kSegs; ++sg) {
+                if (SEGMENTED && !((seg_mask >> sg) & 1u)) continue;
 #pragma unroll
-                for (int k = 0; k < PX; ++k) {
-                    if (u < k || u > k + 2 * RM) continue;
-                    tap(t, cid[k], acc.rg[k], acc.bc[k], (unsigned)(u - first[k]) <= extent[k]);
+                for (int u = sg * kSegW; u < (sg + 1) * kSegW && u < 2 * RM + PX; ++u) {
+                    const f4 t = row[slot<PX>(kMaxR - RM + u)];
+#pragma unroll
+                    for (int k = 0; k < PX; ++k) {
+                        if (u < k || u > k + 2 * RM) continue;
+                        tap(t, cid[k], acc.rg[k], acc.bc[k], (unsigned)(u - first[k]) <= extent[k]);
+                    }
                 }
             }
         }
@@ -260,11 +276,26 @@ __device__ __forceinline__ void rows_static(const f4 *row, const int (&cid)[PX],
 
 template <int PX, int DELTA>
 __device__ __forceinline__ void rows_dispatch(const f4 *row, const int rm, const int (&cid)[PX], const int (&R)[PX], Acc<PX> &acc, const int y_first,
-                                              const int y_last) {
+                                              const int y_last, const uint32_t seg_mask) {
+    const uint32_t every = (1u << ((2 * rm + PX + kSeg - 1) / kSeg)) - 1u;   // all of the row's segments
+    if (seg_mask != every) {
+        switch (rm) {
+#define VRT_DENOISE_CASE(r) \
+    case r:                 \
+        rows_static<PX, r, DELTA, true>(row, cid, R, acc, y_first, y_last, seg_mask); \
+        break;
+            VRT_DENOISE_CASE(1) VRT_DENOISE_CASE(2) VRT_DENOISE_CASE(3) VRT_DENOISE_CASE(4) VRT_DENOISE_CASE(5)
+            VRT_DENOISE_CASE(6) VRT_DENOISE_CASE(7) VRT_DENOISE_CASE(8) VRT_DENOISE_CASE(9) VRT_DENOISE_CASE(10)
+            VRT_DENOISE_CASE(11) VRT_DENOISE_CASE(12) VRT_DENOISE_CASE(13) VRT_DENOISE_CASE(14) VRT_DENOISE_CASE(15)
+            VRT_DENOISE_CASE(16) VRT_DENOISE_CASE(17) VRT_DENOISE_CASE(18) VRT_DENOISE_CASE(19) VRT_DENOISE_CASE(20)
+#undef VRT_DENOISE_CASE
+        }
+        return;
+    }
     switch (rm) {
 #define VRT_DENOISE_CASE(r) \
     case r:                 \
-        rows_static<PX, r, DELTA>(row, cid, R, acc, y_first, y_last); \
+        rows_static<PX, r, DELTA, false>(row, cid, R, acc, y_first, y_last, seg_mask); \
         break;
         VRT_DENOISE_CASE(1) VRT_DENOISE_CASE(2) VRT_DENOISE_CASE(3) VRT_DENOISE_CASE(4) VRT_DENOISE_CASE(5)
         VRT_DENOISE_CASE(6) VRT_DENOISE_CASE(7) VRT_DENOISE_CASE(8) VRT_DENOISE_CASE(9) VRT_DENOISE_CASE(10)
@@ -286,9 +317,11 @@ __device__ __forceinline__ void rows_dispatch(const f4 *row, const int rm, const
 constexpr int kIdSlots = 128;
 struct IdRows {
     int id[kIdSlots];       // 0 = free (a pixel with id 0 is never summed)
-    int lo[kIdSlots], hi[kIdSlots];
+    int lo[kIdSlots], hi[kIdSlots];      // first / last staged row the id occurs in
+    int xlo[kIdSlots], xhi[kIdSlots];    // first / last staged column
     int overflow;
 };
+
 __device__ __forceinline__ uint32_t id_slot(const int id) { return ((uint32_t)id * 2654435761u) >> 25; }   // 7 bits
 
 template <int PX, int TH>
@@ -300,7 +333,11 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
     const int px0 = bx * kTW + threadIdx.x * PX, py = by * kTH + threadIdx.y;
     int cid[PX], R[PX];
     int r_hi = 0, r_lo = kMaxR + 1;
-    for (int i = tid; i < kIdSlots; i += kThreads) { s_ids->id[i] = 0; s_ids->lo[i] = 0x7fffffff; s_ids->hi[i] = -0x7fffffff; }
+    for (int i = tid; i < kIdSlots; i += kThreads) {
+        s_ids->id[i] = 0;
+        s_ids->lo[i] = s_ids->xlo[i] = 0x7fffffff;
+        s_ids->hi[i] = s_ids->xhi[i] = -0x7fffffff;
+    }
     if (tid == 0) s_ids->overflow = 0;
 #pragma unroll
     for (int k = 0; k < PX; ++k) {
@@ -351,9 +388,12 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
     // a thread's taps mostly carry one id after another (its taps lie 3.5 rows apart in one column band): runs of one id are folded
     // in registers and reach the table once per run -- on a close-up where one face fills the tile that is two atomics per thread
     // instead of two per tap on ONE slot
-    int run_id = 0, run_slot = -1, run_lo = 0, run_hi = 0;
+    int run_id = 0, run_slot = -1, run_lo = 0, run_hi = 0, run_xlo = 0, run_xhi = 0;
     const auto flush_run = [&]() {
-        if (run_slot >= 0) { atomicMin(&s_ids->lo[run_slot], run_lo); atomicMax(&s_ids->hi[run_slot], run_hi); }
+        if (run_slot >= 0) {
+            atomicMin(&s_ids->lo[run_slot], run_lo); atomicMax(&s_ids->hi[run_slot], run_hi);
+            atomicMin(&s_ids->xlo[run_slot], run_xlo); atomicMax(&s_ids->xhi[run_slot], run_xhi);
+        }
     };
     for (int b = 0; b < kStageIters; b += kBatch) {
         int vid[kBatch];
@@ -385,11 +425,14 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
                 if (vid[j] == run_id) {
                     run_lo = ly < run_lo ? ly : run_lo;
                     run_hi = ly > run_hi ? ly : run_hi;
+                    run_xlo = lx < run_xlo ? lx : run_xlo;
+                    run_xhi = lx > run_xhi ? lx : run_xhi;
                 } else {
                     flush_run();
                     run_id = vid[j];
                     run_slot = -1;
                     run_lo = run_hi = ly;
+                    run_xlo = run_xhi = lx;
                     uint32_t sl = id_slot(vid[j]);
                     for (int tries = 0; tries < kIdSlots; ++tries, sl = (sl + 1u) & (kIdSlots - 1)) {
                         const int at = s_ids->id[sl];
@@ -422,7 +465,8 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
         const int rm = r_hi, delta = r_hi - r_lo;
         // the rows this wave has to walk: from the lowest first row to the highest last row of its lanes' ids, inside the window
         int y_first = rm, y_last = -rm;   // relative to the lane's own row (all lanes of a wave row share threadIdx.y: window row y is staged row threadIdx.y + kMaxR + y)
-        if (s_ids->overflow) { y_first = -rm; y_last = rm; }
+        int u_first = 2 * kMaxR + PX, u_last = -1;   // tap index of the lane's rows: tap u is staged column kMaxR - rm + u + threadIdx.x * PX
+        if (s_ids->overflow) { y_first = -rm; y_last = rm; u_first = 0; u_last = 2 * rm + PX - 1; }
         else {
 #pragma unroll
             for (int k = 0; k < PX; ++k) {
@@ -433,23 +477,38 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
                 const int f = lo < -R[k] ? -R[k] : lo, l = hi > R[k] ? R[k] : hi;
                 y_first = f < y_first ? f : y_first;
                 y_last = l > y_last ? l : y_last;
+                // columns: pixel k sits at tap index rm + k of its lane's rows; its id occurs in staged columns [xlo, xhi]
+                const int shift = kMaxR - rm + (int)threadIdx.x * PX;
+                const int cf = s_ids->xlo[sl] - shift, cl = s_ids->xhi[sl] - shift;
+                const int uf = cf < rm + k - R[k] ? rm + k - R[k] : cf, ul = cl > rm + k + R[k] ? rm + k + R[k] : cl;
+                u_first = uf < u_first ? uf : u_first;
+                u_last = ul > u_last ? ul : u_last;
             }
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) {
                 const int f = __shfl_xor(y_first, off), l = __shfl_xor(y_last, off);
                 y_first = f < y_first ? f : y_first;
                 y_last = l > y_last ? l : y_last;
+                const int uf = __shfl_xor(u_first, off), ul = __shfl_xor(u_last, off);
+                u_first = uf < u_first ? uf : u_first;
+                u_last = ul > u_last ? ul : u_last;
             }
             y_first = __builtin_amdgcn_readfirstlane(y_first);
             y_last = __builtin_amdgcn_readfirstlane(y_last);
+            u_first = __builtin_amdgcn_readfirstlane(u_first);
+            u_last = __builtin_amdgcn_readfirstlane(u_last);
         }
+        // the segments of kSeg taps that hold a tap some lane needs
+        uint32_t seg_mask = 0u;
+        for (int sg = 0; sg * kSeg < 2 * rm + PX; ++sg)
+            if (sg * kSeg <= u_last && sg * kSeg + kSeg - 1 >= u_first) seg_mask |= 1u << sg;
         const f4 *row = s_rec + (threadIdx.y + kMaxR - rm) * kStride<PX> + threadIdx.x;  // window row -rm, lane column base
         if (delta == 0)
-            rows_dispatch<PX, 0>(row, rm, cid, R, acc, y_first, y_last);
+            rows_dispatch<PX, 0>(row, rm, cid, R, acc, y_first, y_last, seg_mask);
         else if (delta == 1)
-            rows_dispatch<PX, 1>(row, rm, cid, R, acc, y_first, y_last);
+            rows_dispatch<PX, 1>(row, rm, cid, R, acc, y_first, y_last, seg_mask);
         else
-            rows_dispatch<PX, kFull>(row, rm, cid, R, acc, y_first, y_last);
+            rows_dispatch<PX, kFull>(row, rm, cid, R, acc, y_first, y_last, seg_mask);
     }
     if (py >= a.height) return;
 #pragma unroll
