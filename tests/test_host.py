@@ -447,6 +447,69 @@ def test_records_from_tree_equal_records_from_texel_stream(V, product_scenes):
     assert s.records() is None
 
 
+def test_box_records_expand_exactly_the_nodes_that_meet_the_box(V):
+    """vrth_world_box_records (what a box edit hands to vrt_patch_apply): walked beside the full record array from the same node,
+    every child must be the same kind with the same leaf words, except that an INTERNAL child whose cube does not meet the box may
+    be a "keep" record -- and must be one (only the nodes that meet the box are walked); a box covering the world gives the full
+    array, a one-voxel box gives what vrth_world_path_records gives."""
+    import os
+    w = V.World()
+    assert w.load_vox(os.path.join(MAPS, "monu9.vox"))
+    full, _ = w.records()
+    KEEP = 0xffffffff
+    wmin, wmax = (-1023, -1023, -1023), (1024, 1024, 1024)
+    assert np.array_equal(w.box_records([], wmin, tuple(v - 1 for v in wmax)), full)
+    rng = np.random.default_rng(4)
+    for trial in range(12):
+        lo = [int(v) for v in rng.integers(0, 90, size=3)]
+        n = int(rng.choice([1, 1, 4, 16, 40]))
+        hi = [v + n - 1 for v in lo]
+        sparse = w.box_records([], lo, hi)
+        kept = expanded = 0
+        todo = [(0, 0, wmin, wmax)]          # (record in sparse, record in full, node cube)
+        while todo:
+            si, fi, mn, mx = todo.pop()
+            assert sparse[si, 0] == full[fi, 0], "an expanded node carries the same child and leaf masks"
+            mask, leaf = int(full[fi, 0]) & 0xff, (int(full[fi, 0]) >> 8) & 0xff
+            sc, fc = int(sparse[si, 1]), int(full[fi, 1])
+            for ci in range(8):
+                if not (mask >> ci) & 1:
+                    continue
+                cmn, cmx = list(mn), list(mx)
+                for k in range(3):
+                    mid = mn[k] + ((mx[k] - mn[k]) >> 1)
+                    if (ci >> (2 - k)) & 1:
+                        cmn[k] = mid
+                    else:
+                        cmx[k] = mid
+                if (leaf >> ci) & 1:
+                    assert np.array_equal(sparse[sc], full[fc])
+                else:
+                    meets = all(hi[k] >= cmn[k] and lo[k] < cmx[k] for k in range(3))
+                    is_keep = int(sparse[sc, 0]) == KEEP and int(sparse[sc, 1]) == KEEP
+                    assert is_keep == (not meets), (trial, ci, cmn, cmx, lo, hi)
+                    if meets:
+                        expanded += 1
+                        todo.append((sc, fc, cmn, cmx))
+                    else:
+                        kept += 1
+                sc += 1
+                fc += 1
+        assert kept > 0 and expanded > 0 and len(sparse) < len(full)
+        if n == 1:
+            H = V.host_lib()
+            import ctypes as C
+            H.vrth_world_path_records.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int,
+                                                  C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+            p, cnt = C.c_void_p(), C.c_size_t(0)
+            assert H.vrth_world_path_records(w._h, (C.c_uint8 * 16)(), 0, lo[0], lo[1], lo[2], C.byref(p), C.byref(cnt)) == 0
+            one = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(cnt.value, 2)).copy()
+            H.vrth_free(p)
+            assert np.array_equal(one, sparse)
+    with pytest.raises(V.VrtError):
+        w.box_records([], (5, 5, 5), (4, 9, 9))
+
+
 @pytest.mark.parametrize("bounds", [((-1023, -1023, -1023), (1024, 1024, 1024)), ((0, 0, 0), (256, 256, 256)),
                                     ((-7, -3, -5), (123, 70, 99))])
 def test_edit_patches_answer_like_rebuilt_layouts(V, bounds):

@@ -334,6 +334,22 @@ class World:
         L.vrth_free(p)
         return arr, int(d.value)
 
+    def box_records(self, path, lo, hi):
+        """EXTENSION: the sub-tree under the node reached by `path` (child indices from the root) as device records, only the nodes
+        that meet the box of voxels [lo, hi] (inclusive) expanded, the rest "keep" records (vrth_world_box_records) -> uint32[n, 2]"""
+        L = host_lib()
+        L.vrth_world_box_records.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        p, n = C.c_void_p(), C.c_size_t(0)
+        pa = (C.c_uint8 * 16)(*list(path))
+        r = L.vrth_world_box_records(self._h, pa, len(path), (C.c_int32 * 3)(*[int(v) for v in lo]), (C.c_int32 * 3)(*[int(v) for v in hi]),
+                                     C.byref(p), C.byref(n))
+        if r != 0:
+            raise VrtError(f"vrth_world_box_records failed ({r})")
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n.value, 2)).copy()
+        L.vrth_free(p)
+        return arr
+
     def fill_heights(self, heights, x0, z0, nx, nz, band=8, floor_y=20):
         """config 4 terrain: the reference's generator (src/main.cpp:487-503) over a uint16 height field [size_z, size_x]"""
         h = np.ascontiguousarray(heights, dtype=np.uint16)
