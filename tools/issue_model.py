@@ -119,7 +119,7 @@ def build(summary_path):
     import vrt_import
     S = json.load(open(summary_path))
     consts = probe_constants()
-    model = {"_note": __doc__.split("\n\n")[2] if False else "see tools/issue_model.py; inputs: " + os.path.relpath(summary_path, ROOT) + ", profiles/r03_valu_rate.json",
+    model = {"_note": "see tools/issue_model.py; inputs: " + os.path.relpath(summary_path, ROOT) + ", profiles/r03_valu_rate.json",
              "simds": 1024, "lib_stamp": bench.lib_stamp(vrt_import.vrt()), **{k: consts[k] for k in ("issue_slot_cycles", "half_pipe_cycles", "salu_cycles")},
              "probe_rows": consts["probe_rows"], "workloads": {}}
     traffic_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -154,12 +154,12 @@ static bool tree_is_opaque(const std::vector<vrt::Record> &rec) {
 
 int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_rows, int row_stride, int compact,
             int mode, void *d_rgba, void *d_id, hipStream_t s, const vrt_view *views, int n_views) {
-    if (!c->have_scene) return fail(c, VRT_E_STATE, "vrt_dispatch: no octree uploaded (call vrt_upload_octree first)");
-    if (c->batch.open) return fail(c, VRT_E_STATE, "vrt_dispatch: a patch batch is open (call vrt_patch_end first)");
-    if (!views && !c->have_camera) return fail(c, VRT_E_STATE, "vrt_dispatch: no camera set (call vrt_set_camera first)");
-    if (n_views < 1 || n_views > vrt::kMaxViews) return fail(c, VRT_E_INVALID, "vrt_dispatch_views: 1 to 4 views per launch");
+    if (!c->have_scene) return vrt_fail(c, VRT_E_STATE, "vrt_dispatch: no octree uploaded (call vrt_upload_octree first)");
+    if (c->batch.open) return vrt_fail(c, VRT_E_STATE, "vrt_dispatch: a patch batch is open (call vrt_patch_end first)");
+    if (!views && !c->have_camera) return vrt_fail(c, VRT_E_STATE, "vrt_dispatch: no camera set (call vrt_set_camera first)");
+    if (n_views < 1 || n_views > vrt::kMaxViews) return vrt_fail(c, VRT_E_INVALID, "vrt_dispatch_views: 1 to 4 views per launch");
     if (mode != VRT_MODE_PRIMARY && mode != VRT_MODE_PRIMARY_SHADOW && mode != VRT_MODE_FULL)
-        return fail(c, VRT_E_INVALID, "unknown mode");
+        return vrt_fail(c, VRT_E_INVALID, "unknown mode");
     if (n_rows <= 0) return VRT_OK;
     {
         const int ra = ensure_analysis(c);
@@ -402,7 +402,7 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     else
 #endif
     e = vrt::launch::trace(mode, v, a, vs, (int)grid, lds_bytes, s, ev0, ev1);
-    if (e != hipSuccess) return fail(c, VRT_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return vrt_fail(c, VRT_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     if (st) {
         ++st->launches;
         if (measure) {
@@ -423,7 +423,7 @@ int vrt_dispatch_rows(vrt_ctx *c, int width, int height, int row_begin, int row_
                       void *d_id_dist, void *stream) {
     int r = check_frame(c, width, height);
     if (r) return r;
-    if (row_begin < 0 || row_end > height || row_begin > row_end) return fail(c, VRT_E_INVALID, "vrt_dispatch_rows: bad row range");
+    if (row_begin < 0 || row_end > height || row_begin > row_end) return vrt_fail(c, VRT_E_INVALID, "vrt_dispatch_rows: bad row range");
     VRT_HIP(c, hipSetDevice(c->device));
     const int n = row_end - row_begin;
     return enqueue(c, width, height, row_begin, n, n > 0 ? n : 1, 0, 0, mode, d_rgba8, d_id_dist,
@@ -446,7 +446,7 @@ int vrt_dispatch_shard(vrt_ctx *c, int width, int height, int tile_rows, int sha
     int r = check_frame(c, width, height);
     if (r) return r;
     const int rows = vrt_shard_rows(height, tile_rows, shard, n_shards);
-    if (rows < 0) return fail(c, VRT_E_INVALID, "vrt_dispatch_shard: bad tile_rows/shard/n_shards");
+    if (rows < 0) return vrt_fail(c, VRT_E_INVALID, "vrt_dispatch_shard: bad tile_rows/shard/n_shards");
     VRT_HIP(c, hipSetDevice(c->device));
     return enqueue(c, width, height, shard * tile_rows, rows, tile_rows, tile_rows * n_shards, 1, mode, d_rgba8,
                    d_id_dist, stream ? (hipStream_t)stream : c->stream);
@@ -457,7 +457,7 @@ int vrt_dispatch_tiles(vrt_ctx *c, int width, int height, int tile_rows, int sha
     int r = check_frame(c, width, height);
     if (r) return r;
     const int rows = vrt_shard_rows(height, tile_rows, shard, n_shards);
-    if (rows < 0) return fail(c, VRT_E_INVALID, "vrt_dispatch_tiles: bad tile_rows/shard/n_shards");
+    if (rows < 0) return vrt_fail(c, VRT_E_INVALID, "vrt_dispatch_tiles: bad tile_rows/shard/n_shards");
     VRT_HIP(c, hipSetDevice(c->device));
     // the shard's tiles at their frame rows (compact = 0): the frame may be local, a peer's, or an IPC mapping
     return enqueue(c, width, height, shard * tile_rows, rows, tile_rows, tile_rows * n_shards, 0, mode, d_frame_rgba8, d_frame_id_dist,
@@ -468,9 +468,9 @@ int vrt_dispatch_views(vrt_ctx *c, int width, int height, int tile_rows, int sha
                        const vrt_view *views, int n_views, void *stream) {
     int r = check_frame(c, width, height);
     if (r) return r;
-    if (!views) return fail(c, VRT_E_INVALID, "vrt_dispatch_views: null views");
+    if (!views) return vrt_fail(c, VRT_E_INVALID, "vrt_dispatch_views: null views");
     const int rows = vrt_shard_rows(height, tile_rows, shard, n_shards);
-    if (rows < 0) return fail(c, VRT_E_INVALID, "vrt_dispatch_views: bad tile_rows/shard/n_shards");
+    if (rows < 0) return vrt_fail(c, VRT_E_INVALID, "vrt_dispatch_views: bad tile_rows/shard/n_shards");
     VRT_HIP(c, hipSetDevice(c->device));
     return enqueue(c, width, height, shard * tile_rows, rows, tile_rows, tile_rows * n_shards, 1, mode, nullptr, nullptr,
                    stream ? (hipStream_t)stream : c->stream, views, n_views);
@@ -493,7 +493,7 @@ int vrt_dispatch(vrt_ctx *c, int width, int height, int mode, uint8_t *out_rgba8
 }
 
 int vrt_dispatch_wait(vrt_ctx *c, int ticket) {
-    if (!c || ticket < 0 || ticket > 1) return c ? fail(c, VRT_E_INVALID, "vrt_dispatch_wait: ticket") : VRT_E_INVALID;
+    if (!c || ticket < 0 || ticket > 1) return c ? vrt_fail(c, VRT_E_INVALID, "vrt_dispatch_wait: ticket") : VRT_E_INVALID;
     vrt_ctx::AsyncLane &ln = c->lane[ticket];
     if (!ln.busy) return VRT_OK;
     VRT_HIP(c, hipSetDevice(c->device));
@@ -505,7 +505,7 @@ int vrt_dispatch_wait(vrt_ctx *c, int ticket) {
 int vrt_dispatch_async(vrt_ctx *c, int width, int height, int mode, uint8_t *out_rgba8, int32_t *out_id_dist, int *ticket) {
     int r = check_frame(c, width, height);
     if (r) return r;
-    if (!ticket) return fail(c, VRT_E_INVALID, "vrt_dispatch_async: null ticket");
+    if (!ticket) return vrt_fail(c, VRT_E_INVALID, "vrt_dispatch_async: null ticket");
     VRT_HIP(c, hipSetDevice(c->device));
     const int k = c->next_lane;
     vrt_ctx::AsyncLane &ln = c->lane[k];
@@ -519,7 +519,7 @@ int vrt_dispatch_async(vrt_ctx *c, int width, int height, int mode, uint8_t *out
     if (px > ln.pixels) {
         void *a = nullptr, *b = nullptr;
         VRT_HIP(c, hipMalloc(&a, px * 4));
-        if (hipMalloc(&b, px * 8) != hipSuccess) { (void)hipFree(a); return fail(c, VRT_E_HIP, "vrt_dispatch_async: hipMalloc"); }
+        if (hipMalloc(&b, px * 8) != hipSuccess) { (void)hipFree(a); return vrt_fail(c, VRT_E_HIP, "vrt_dispatch_async: hipMalloc"); }
         (void)hipFree(ln.d_rgba);
         (void)hipFree(ln.d_id);
         ln.d_rgba = a; ln.d_id = b; ln.pixels = px;
@@ -553,8 +553,8 @@ int vrt_dispatch_timed(vrt_ctx *c, int width, int height, int row_begin, int row
                        void *d_id_dist, void *stream, int iters, float *ms_out) {
     int r = check_frame(c, width, height);
     if (r) return r;
-    if (iters < 1 || !ms_out) return fail(c, VRT_E_INVALID, "vrt_dispatch_timed: iters/ms_out");
-    if (row_begin < 0 || row_end > height || row_begin >= row_end) return fail(c, VRT_E_INVALID, "vrt_dispatch_timed: bad row range");
+    if (iters < 1 || !ms_out) return vrt_fail(c, VRT_E_INVALID, "vrt_dispatch_timed: iters/ms_out");
+    if (row_begin < 0 || row_end > height || row_begin >= row_end) return vrt_fail(c, VRT_E_INVALID, "vrt_dispatch_timed: bad row range");
     VRT_HIP(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     std::vector<hipEvent_t> ev((size_t)iters * 2, nullptr);
@@ -572,7 +572,7 @@ int vrt_dispatch_timed(vrt_ctx *c, int width, int height, int row_begin, int row
     for (int i = 0; i < iters && rc == VRT_OK && he == hipSuccess; ++i) he = hipEventElapsedTime(&ms_out[i], ev[2 * i], ev[2 * i + 1]);
     for (auto &e : ev)
         if (e) (void)hipEventDestroy(e);   // on every path
-    if (rc == VRT_OK && he != hipSuccess) rc = fail(c, VRT_E_HIP, std::string("vrt_dispatch_timed: ") + hipGetErrorString(he));
+    if (rc == VRT_OK && he != hipSuccess) rc = vrt_fail(c, VRT_E_HIP, std::string("vrt_dispatch_timed: ") + hipGetErrorString(he));
     return rc;
 }
 
@@ -610,7 +610,7 @@ int vrt_profile_read(vrt_ctx *c, float *ms_out, int cap) {
 
 int vrt_set_tile_scheduling(vrt_ctx *c, int period) {
     if (!c) return VRT_E_INVALID;
-    if (period < 0) return fail(c, VRT_E_INVALID, "vrt_set_tile_scheduling: period must be >= 0");
+    if (period < 0) return vrt_fail(c, VRT_E_INVALID, "vrt_set_tile_scheduling: period must be >= 0");
     c->sched_period = period;
     return VRT_OK;
 }
@@ -636,11 +636,11 @@ int vrt_set_option(vrt_ctx *c, int option, int value) {
             return VRT_OK;
         case VRT_OPT_DISPLAY_KERNEL:
             if (value == 0 || (value == 1 && VRT_AB)) { c->denoise_variant = value; return VRT_OK; }
-            return fail(c, VRT_E_INVALID, "vrt_set_option: the one-pixel-per-lane display kernel exists in A/B builds only (make AB=1)");
+            return vrt_fail(c, VRT_E_INVALID, "vrt_set_option: the one-pixel-per-lane display kernel exists in A/B builds only (make AB=1)");
         default:
-            return fail(c, VRT_E_INVALID, "vrt_set_option: unknown option");
+            return vrt_fail(c, VRT_E_INVALID, "vrt_set_option: unknown option");
     }
-    return fail(c, VRT_E_INVALID, "vrt_set_option: value out of range");
+    return vrt_fail(c, VRT_E_INVALID, "vrt_set_option: value out of range");
 }
 
 int vrt_set_tile_order(vrt_ctx *c, int enable, const void *d_group_order, void *d_tile_cost) {

@@ -14,7 +14,7 @@ extern "C" {
 int vrt_denoise(vrt_ctx *c, int width, int height, const void *d_rgba8, const void *d_id_dist, void *d_out_rgba8, void *stream) {
     int r = check_frame(c, width, height);
     if (r) return r;
-    if (!d_rgba8 || !d_id_dist || !d_out_rgba8 || d_rgba8 == d_out_rgba8) return fail(c, VRT_E_INVALID, "vrt_denoise: null or aliased buffers");
+    if (!d_rgba8 || !d_id_dist || !d_out_rgba8 || d_rgba8 == d_out_rgba8) return vrt_fail(c, VRT_E_INVALID, "vrt_denoise: null or aliased buffers");
     VRT_HIP(c, hipSetDevice(c->device));
     vrt::launch::Denoise d{d_rgba8, d_id_dist, d_out_rgba8, width, height, nullptr, nullptr};
     const hipStream_t s = stream ? (hipStream_t)stream : c->stream;
@@ -51,7 +51,7 @@ int vrt_denoise(vrt_ctx *c, int width, int height, const void *d_rgba8, const vo
 int vrt_denoise_host(vrt_ctx *c, int width, int height, const uint8_t *rgba8, const int32_t *id_dist, uint8_t *out_rgba8) {
     int r = check_frame(c, width, height);
     if (r) return r;
-    if (!rgba8 || !id_dist || !out_rgba8) return fail(c, VRT_E_INVALID, "vrt_denoise_host: null buffer");
+    if (!rgba8 || !id_dist || !out_rgba8) return vrt_fail(c, VRT_E_INVALID, "vrt_denoise_host: null buffer");
     VRT_HIP(c, hipSetDevice(c->device));
     const size_t px = (size_t)width * (size_t)height;
     r = ensure_scratch(c, px);
@@ -69,7 +69,7 @@ int vrt_dispatch_frame(vrt_ctx *c, int width, int height, int mode, uint8_t *out
                        int32_t *out_id_dist) {
     int r = check_frame(c, width, height);
     if (r) return r;
-    if (!out_shown_rgba8) return fail(c, VRT_E_INVALID, "vrt_dispatch_frame: null output");
+    if (!out_shown_rgba8) return vrt_fail(c, VRT_E_INVALID, "vrt_dispatch_frame: null output");
     VRT_HIP(c, hipSetDevice(c->device));
     const size_t px = (size_t)width * (size_t)height;
     r = ensure_scratch(c, px);

@@ -196,13 +196,12 @@ inline int vrt_fail(vrt_ctx *c, int code, const std::string &msg) {
     if (c) c->err = msg;
     return code;
 }
-#define fail vrt_fail
 
 #define VRT_HIP(c, call)                                                                   \
     do {                                                                                   \
         hipError_t e_ = (call);                                                            \
         if (e_ != hipSuccess)                                                              \
-            return fail((c), VRT_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+            return vrt_fail((c), VRT_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
 namespace vrt_internal {

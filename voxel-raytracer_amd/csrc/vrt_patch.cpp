@@ -24,7 +24,7 @@ int patch_host(vrt_ctx *c, const vrt_patch &patch, const uint32_t *subtree_recor
     for (int k = 0; k < 3; ++k) { lo[k] = c->params.world_min[k]; hi[k] = c->params.world_max[k]; }
     for (int d = 0; d < patch.depth; ++d) {   // find A again from the path (the plan carries no pointers into this context)
         const uint32_t ci = patch.path[d];
-        if (ci > 7) return fail(c, VRT_E_INVALID, "vrt_patch_apply: bad path");
+        if (ci > 7) return vrt_fail(c, VRT_E_INVALID, "vrt_patch_apply: bad path");
         for (int k = 0; k < 3; ++k) {
             const int mid = lo[k] + ((hi[k] - lo[k]) >> 1);
             if ((ci >> (2 - k)) & 1u) lo[k] = mid; else hi[k] = mid;
@@ -34,11 +34,11 @@ int patch_host(vrt_ctx *c, const vrt_patch &patch, const uint32_t *subtree_recor
     const bool wide_now = c->wide_ok && !bt.wide_invalid;
     if (!vrt::plan_patch(c->host_records, c->wide, wide_now, c->params.world_min, c->params.world_max, lo, patch.depth, site) ||
         site.depth != patch.depth || std::memcmp(site.path, patch.path, (size_t)patch.depth) != 0)
-        return fail(c, VRT_E_STATE, "vrt_patch_apply: the path does not name a patchable node of the uploaded tree");
+        return vrt_fail(c, VRT_E_STATE, "vrt_patch_apply: the path does not name a patchable node of the uploaded tree");
     vrt::PatchRanges rg;
     std::string why;
     if (!vrt::apply_patch(c->host_records, c->wide, wide_now, site, reinterpret_cast<const vrt::Record *>(subtree_records), n_records, rg, why))
-        return fail(c, VRT_E_MALFORMED, "vrt_patch_apply: " + why);   // apply_patch modifies nothing when it refuses
+        return vrt_fail(c, VRT_E_MALFORMED, "vrt_patch_apply: " + why);   // apply_patch modifies nothing when it refuses
     bt.dirty = true;
     c->scene_opaque_valid = false;   // the tree changed: what the two-pass path tracer may assume about it is re-derived
     bt.rewritten_records.push_back(site.record);
@@ -104,9 +104,9 @@ int patch_device(vrt_ctx *c) {
 extern "C" {
 
 int vrt_patch_plan_box(vrt_ctx *c, const int32_t lo[3], const int32_t hi[3], int max_depth, vrt_patch *out) {
-    if (!c || !out || !lo || !hi) return c ? fail(c, VRT_E_INVALID, "vrt_patch_plan: null argument") : VRT_E_INVALID;
-    if (lo[0] > hi[0] || lo[1] > hi[1] || lo[2] > hi[2]) return fail(c, VRT_E_INVALID, "vrt_patch_plan_box: lo > hi");
-    if (!c->have_scene) return fail(c, VRT_E_STATE, "vrt_patch_plan: no octree uploaded");
+    if (!c || !out || !lo || !hi) return c ? vrt_fail(c, VRT_E_INVALID, "vrt_patch_plan: null argument") : VRT_E_INVALID;
+    if (lo[0] > hi[0] || lo[1] > hi[1] || lo[2] > hi[2]) return vrt_fail(c, VRT_E_INVALID, "vrt_patch_plan_box: lo > hi");
+    if (!c->have_scene) return vrt_fail(c, VRT_E_STATE, "vrt_patch_plan: no octree uploaded");
     VRT_HIP(c, hipSetDevice(c->device));
     int r = ensure_analysis(c);
     if (r) return r;
@@ -138,7 +138,7 @@ int vrt_patch_plan_box(vrt_ctx *c, const int32_t lo[3], const int32_t hi[3], int
         }
         md = site.depth - 1;
     }
-    return fail(c, VRT_E_STATE, "vrt_patch_plan: no patchable ancestor (full upload needed)");
+    return vrt_fail(c, VRT_E_STATE, "vrt_patch_plan: no patchable ancestor (full upload needed)");
 }
 
 int vrt_patch_plan(vrt_ctx *c, int x, int y, int z, int max_depth, vrt_patch *out) {
@@ -148,8 +148,8 @@ int vrt_patch_plan(vrt_ctx *c, int x, int y, int z, int max_depth, vrt_patch *ou
 
 int vrt_patch_begin(vrt_ctx *c) {
     if (!c) return VRT_E_INVALID;
-    if (!c->have_scene) return fail(c, VRT_E_STATE, "vrt_patch_begin: no octree uploaded");
-    if (c->batch.open) return fail(c, VRT_E_STATE, "vrt_patch_begin: a batch is already open");
+    if (!c->have_scene) return vrt_fail(c, VRT_E_STATE, "vrt_patch_begin: no octree uploaded");
+    if (c->batch.open) return vrt_fail(c, VRT_E_STATE, "vrt_patch_begin: a batch is already open");
     VRT_HIP(c, hipSetDevice(c->device));
     const int r = ensure_analysis(c);
     if (r) return r;
@@ -162,15 +162,15 @@ int vrt_patch_begin(vrt_ctx *c) {
 
 int vrt_patch_end(vrt_ctx *c) {
     if (!c) return VRT_E_INVALID;
-    if (!c->batch.open) return fail(c, VRT_E_STATE, "vrt_patch_end: no batch open");
+    if (!c->batch.open) return vrt_fail(c, VRT_E_STATE, "vrt_patch_end: no batch open");
     VRT_HIP(c, hipSetDevice(c->device));
     return patch_device(c);
 }
 
 int vrt_patch_apply(vrt_ctx *c, const vrt_patch *patch, const uint32_t *subtree_records, size_t n_records) {
-    if (!c || !patch || !subtree_records) return c ? fail(c, VRT_E_INVALID, "vrt_patch_apply: null argument") : VRT_E_INVALID;
-    if (!c->have_scene) return fail(c, VRT_E_STATE, "vrt_patch_apply: no octree uploaded");
-    if (patch->depth < 1 || patch->depth > 15) return fail(c, VRT_E_INVALID, "vrt_patch_apply: depth out of range");
+    if (!c || !patch || !subtree_records) return c ? vrt_fail(c, VRT_E_INVALID, "vrt_patch_apply: null argument") : VRT_E_INVALID;
+    if (!c->have_scene) return vrt_fail(c, VRT_E_STATE, "vrt_patch_apply: no octree uploaded");
+    if (patch->depth < 1 || patch->depth > 15) return vrt_fail(c, VRT_E_INVALID, "vrt_patch_apply: depth out of range");
     const bool single = !c->batch.open;
     if (single) {
         const int r = vrt_patch_begin(c);
@@ -189,9 +189,9 @@ int vrt_patch_apply(vrt_ctx *c, const vrt_patch *patch, const uint32_t *subtree_
 // at the next dispatch. No texel stream is involved; u_texDim and the stream's texel count are those the patches kept.
 int vrt_compact(vrt_ctx *c) {
     if (!c) return VRT_E_INVALID;
-    if (!c->have_scene) return fail(c, VRT_E_STATE, "vrt_compact: no octree uploaded");
+    if (!c->have_scene) return vrt_fail(c, VRT_E_STATE, "vrt_compact: no octree uploaded");
     // the batch's bookkeeping (records_before, rewritten records, repointed cells) indexes the arrays compaction re-lays
-    if (c->batch.open) return fail(c, VRT_E_STATE, "vrt_compact: a patch batch is open (call vrt_patch_end first)");
+    if (c->batch.open) return vrt_fail(c, VRT_E_STATE, "vrt_compact: a patch batch is open (call vrt_patch_end first)");
     VRT_HIP(c, hipSetDevice(c->device));
     VRT_HIP(c, hipDeviceSynchronize());   // dispatches in flight read the old arrays
     vrt::compact_records(c->host_records);

@@ -19,7 +19,7 @@ namespace vrt_internal {
 int check_frame(vrt_ctx *c, int width, int height) {
     if (!c) return VRT_E_INVALID;
     if (width < 1 || height < 1 || (long)width * (long)height > (1L << 30))
-        return fail(c, VRT_E_INVALID, "width/height out of range");
+        return vrt_fail(c, VRT_E_INVALID, "width/height out of range");
     return VRT_OK;
 }
 
@@ -47,7 +47,7 @@ int reserve_cells(vrt_ctx *c, size_t n_cells) {
 // cells [from, from + n) of c->wide to the device in both forms; blocking (callers have synchronised the device)
 int upload_cells(vrt_ctx *c, size_t from, size_t n) {
     if (n == 0) return VRT_OK;
-    if (from + n > c->wide.cells.size() || from + n > c->cells_capacity) return fail(c, VRT_E_STATE, "upload_cells: range outside the wide layout");
+    if (from + n > c->wide.cells.size() || from + n > c->cells_capacity) return vrt_fail(c, VRT_E_STATE, "upload_cells: range outside the wide layout");
     VRT_HIP(c, hipMemcpy(c->d_cells + from, c->wide.cells.data() + from, n * sizeof(vrt::WideCell), hipMemcpyHostToDevice));
     std::vector<vrt::WideCell> c4(n);
     for (size_t i = 0; i < n; ++i) c4[i] = vrt::to_cell4(c->wide.cells[from + i]);
@@ -224,15 +224,15 @@ void vrt_destroy(vrt_ctx *c) {
 const char *vrt_last_error(const vrt_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
 int vrt_set_params(vrt_ctx *c, const vrt_params *p) {
-    if (!c || !p) return c ? fail(c, VRT_E_INVALID, "vrt_set_params: null params") : VRT_E_INVALID;
+    if (!c || !p) return c ? vrt_fail(c, VRT_E_INVALID, "vrt_set_params: null params") : VRT_E_INVALID;
     for (int i = 0; i < 3; ++i)
-        if (p->world_max[i] < p->world_min[i]) return fail(c, VRT_E_INVALID, "vrt_set_params: world_max < world_min");
+        if (p->world_max[i] < p->world_min[i]) return vrt_fail(c, VRT_E_INVALID, "vrt_set_params: world_max < world_min");
     bool bounds_change = false;
     for (int i = 0; i < 3; ++i)
         bounds_change = bounds_change || p->world_min[i] != c->params.world_min[i] || p->world_max[i] != c->params.world_max[i];
     // an open batch holds indices into the layouts the world bounds shaped (records_before, cells_before, repointed cells)
     if (bounds_change && c->batch.open)
-        return fail(c, VRT_E_STATE, "vrt_set_params: the world bounds cannot change while a patch batch is open (call vrt_patch_end first)");
+        return vrt_fail(c, VRT_E_STATE, "vrt_set_params: the world bounds cannot change while a patch batch is open (call vrt_patch_end first)");
     c->params = *p;
     if (bounds_change) c->analysis_valid = false;
     return VRT_OK;
@@ -240,13 +240,13 @@ int vrt_set_params(vrt_ctx *c, const vrt_params *p) {
 
 int vrt_upload_octree(vrt_ctx *c, const uint8_t *texels, size_t used_bytes, uint32_t tex_dim) {
     if (!c) return VRT_E_INVALID;
-    if (c->batch.open) return fail(c, VRT_E_STATE, "vrt_upload_octree: a patch batch is open (call vrt_patch_end first)");
-    if (used_bytes % 4 != 0) return fail(c, VRT_E_INVALID, "vrt_upload_octree: used_bytes must be a multiple of 4");
-    if (used_bytes / 4 > (1u << 23)) return fail(c, VRT_E_MALFORMED, "vrt_upload_octree: more than 2^23 texels cannot be addressed by 23-bit node pointers");
+    if (c->batch.open) return vrt_fail(c, VRT_E_STATE, "vrt_upload_octree: a patch batch is open (call vrt_patch_end first)");
+    if (used_bytes % 4 != 0) return vrt_fail(c, VRT_E_INVALID, "vrt_upload_octree: used_bytes must be a multiple of 4");
+    if (used_bytes / 4 > (1u << 23)) return vrt_fail(c, VRT_E_MALFORMED, "vrt_upload_octree: more than 2^23 texels cannot be addressed by 23-bit node pointers");
     if (tex_dim == 0) tex_dim = 1;
     vrt::Layout lay;
     std::string err;
-    if (!vrt::build_layout(texels, used_bytes, lay, err)) return fail(c, VRT_E_MALFORMED, "vrt_upload_octree: " + err);
+    if (!vrt::build_layout(texels, used_bytes, lay, err)) return vrt_fail(c, VRT_E_MALFORMED, "vrt_upload_octree: " + err);
     VRT_HIP(c, hipSetDevice(c->device));
     const size_t bytes = lay.records.size() * sizeof(vrt::Record);
     if (bytes > c->nodes_capacity) {
@@ -284,8 +284,8 @@ int vrt_upload_octree(vrt_ctx *c, const uint8_t *texels, size_t used_bytes, uint
 // it the stream's 23-bit pointer limit and the flatten + re-parse on every edit.
 int vrt_upload_records(vrt_ctx *c, const uint32_t *records, size_t n_records, uint32_t tex_dim) {
     if (!c) return VRT_E_INVALID;
-    if (c->batch.open) return fail(c, VRT_E_STATE, "vrt_upload_records: a patch batch is open (call vrt_patch_end first)");
-    if (!records || n_records == 0 || n_records > (1ull << 31)) return fail(c, VRT_E_INVALID, "vrt_upload_records: bad record array");
+    if (c->batch.open) return vrt_fail(c, VRT_E_STATE, "vrt_upload_records: a patch batch is open (call vrt_patch_end first)");
+    if (!records || n_records == 0 || n_records > (1ull << 31)) return vrt_fail(c, VRT_E_INVALID, "vrt_upload_records: bad record array");
     if (tex_dim == 0) tex_dim = 1;
     // structural check: every child index lies after its parent (level order) and inside the array, so a
     // descent always terminates; depth is bounded by the same 16-iteration rule as the texel path
@@ -303,12 +303,12 @@ int vrt_upload_records(vrt_ctx *c, const uint32_t *records, size_t n_records, ui
         if (depth[i] >= 15) { recs[i].w0 = 0; mask = 0; }
         const uint32_t n_child = (uint32_t)__builtin_popcount(mask);
         if (n_child == 0) continue;
-        if (base <= i || (size_t)base + n_child > n_records) return fail(c, VRT_E_MALFORMED, "vrt_upload_records: child index out of order or range");
+        if (base <= i || (size_t)base + n_child > n_records) return vrt_fail(c, VRT_E_MALFORMED, "vrt_upload_records: child index out of order or range");
         uint32_t rank = 0;
         for (uint32_t ci = 0; ci < 8; ++ci) {
             if (!((mask >> ci) & 1u)) continue;
             const size_t idx = (size_t)base + rank++;
-            if (kind[idx] != 0) return fail(c, VRT_E_MALFORMED, "vrt_upload_records: a record has two parents");
+            if (kind[idx] != 0) return vrt_fail(c, VRT_E_MALFORMED, "vrt_upload_records: a record has two parents");
             kind[idx] = ((leaf_mask >> ci) & 1u) ? 2 : 1;
             depth[idx] = (uint8_t)(depth[i] + 1);
             if (depth[idx] > max_depth) max_depth = depth[idx];
@@ -352,7 +352,7 @@ int vrt_get_scene_info(const vrt_ctx *c, vrt_scene_info *info) {
 
 int vrt_set_camera(vrt_ctx *c, const float inv_projection[16], const float inv_view[16], const float camera_pos[4]) {
     if (!c) return VRT_E_INVALID;
-    if (!inv_projection || !inv_view || !camera_pos) return fail(c, VRT_E_INVALID, "vrt_set_camera: null pointer");
+    if (!inv_projection || !inv_view || !camera_pos) return vrt_fail(c, VRT_E_INVALID, "vrt_set_camera: null pointer");
     std::memcpy(c->inv_proj, inv_projection, sizeof c->inv_proj);
     std::memcpy(c->inv_view, inv_view, sizeof c->inv_view);
     std::memcpy(c->cam_pos, camera_pos, sizeof c->cam_pos);
@@ -366,9 +366,9 @@ int vrt_variant_available(int variant) {
 
 int vrt_set_variant(vrt_ctx *c, int variant) {
     if (!c) return VRT_E_INVALID;
-    if (variant < 0 || variant >= kNumVariants) return fail(c, VRT_E_INVALID, "vrt_set_variant: unknown variant");
+    if (variant < 0 || variant >= kNumVariants) return vrt_fail(c, VRT_E_INVALID, "vrt_set_variant: unknown variant");
     if (!VRT_AB && !kVariantShipped[variant])
-        return fail(c, VRT_E_INVALID, "vrt_set_variant: an A/B variant; this library was built without them (make AB=1)");
+        return vrt_fail(c, VRT_E_INVALID, "vrt_set_variant: an A/B variant; this library was built without them (make AB=1)");
     c->variant = variant;
     return VRT_OK;
 }
