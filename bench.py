@@ -266,14 +266,17 @@ PREROLL = int(os.environ.get("VRT_BENCH_PREROLL", "512"))
 
 
 def lib_stamp(V):
-    """what the quoted PMC figures are tied to: the kernels' sources (a figure collected on another build is dropped)"""
+    """What the quoted PMC figures are tied to: the compiled tracer kernels -- a hash of the three launch objects the shipped library is
+    linked from (csrc/build/vrt_launch_{primary,shadow,full}.o; hipcc output is reproducible, comments and the display pass do not
+    enter). None when the objects are not there (a library built some other way): nothing is dropped then."""
     import hashlib
     h = hashlib.sha256()
-    csrc = os.path.join(ROOT, "voxel-raytracer_amd", "csrc")
-    for f in sorted(os.listdir(csrc)):   # what shapes the TRACE kernels and their launches (not the display pass, not the multi-GPU code)
-        if (f.startswith(("vrt_kernels", "vrt_launch_")) and f != "vrt_launch_misc.hip") or f in (
-                "vrt_common.hip.h", "vrt_full.hip.h", "vrt_args.h", "vrt_layout.h", "vrt_layout.cpp", "vrt_dispatch.cpp"):
-            h.update(open(os.path.join(csrc, f), "rb").read())
+    build = os.path.join(ROOT, "voxel-raytracer_amd", "csrc", "build")
+    try:
+        for f in ("vrt_launch_primary.o", "vrt_launch_shadow.o", "vrt_launch_full.o"):
+            h.update(open(os.path.join(build, f), "rb").read())
+    except OSError:
+        return None
     return h.hexdigest()[:16]
 
 
@@ -299,7 +302,7 @@ def issue_roofline(V, workload_key, kernel_ms_mean, share=1.0):
     e = m.get("workloads", {}).get(workload_key)
     if not e or not e.get("busy_cycles"):
         return None
-    if m.get("lib_stamp") and m["lib_stamp"] != lib_stamp(V):
+    if m.get("lib_stamp") and lib_stamp(V) and m["lib_stamp"] != lib_stamp(V):
         return {"stale": True, "note": "profiles/r03_issue_model.json was collected on different kernel sources; not quoted"}
     n_valu = e["valu_insts_per_launch"] * share
     t_slot = n_valu * m["issue_slot_cycles"] / m["simds"] / (e["clock_ghz"] * 1e9) * 1e3

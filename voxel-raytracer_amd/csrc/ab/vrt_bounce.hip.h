@@ -134,7 +134,7 @@ VRT_DEV void finish(const KArgs &a, const Lane &l, bool hit, uint32_t *out_rgba)
     out_rgba[out_offset] = unorm8(fc[0]) | (unorm8(fc[1]) << 8) | (unorm8(fc[2]) << 16) | (255u << 24);
 }
 
-// One wave per workgroup; the grid is sized to fill the chip once (vrt_capi.hip). Every wave reaches the exit: the loop
+// One wave per workgroup; the grid is sized to fill the chip once (vrt_launch_ab.hip). Every wave reaches the exit: the loop
 // ends when no lane marches and all queues have been handed out.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void bounce_kernel(const KArgs a, const Args b) {
     T::Ctx c;

@@ -26,7 +26,7 @@ struct View {
     uint32_t first_w0, first_w1, first_node, first_anode;
     int first_s, first_as, first_valid;
     // Ray generation with its per-column and per-row parts made once per projection by the dispatcher (ray_table() in
-    // vrt_capi.hip): when the inverse projection has the shape every perspective or orthographic matrix gives it -- x
+    // vrt_dispatch.cpp, vrt_raygen.cpp): when the inverse projection has the shape every perspective or orthographic matrix gives it -- x
     // depends on the column only, y on the row only, z and w on neither -- gen_x[px], gen_y[py], gen_z hold view.xyz / w
     // of comp:630-634 (same float operations, made on the host), and gen_fast says that they do and that every
     // normalisation of the prologue stays inside the range where 1/x and sqrt need no range scaling (primary_ray_dir()).
@@ -62,7 +62,7 @@ struct KArgs {
     //   y = row0 + (j / tile_rows) * row_stride + (j % tile_rows)
     int row0, n_rows, tile_rows, row_stride;
     int compact;              // 1: outputs indexed by local row j, 0: by frame row y
-    // the two index divisions of a wave's prologue, prepared by the host (enqueue() in vrt_capi.hip):
+    // the two index divisions of a wave's prologue, prepared by the host (enqueue() in vrt_dispatch.cpp):
     uint32_t tiles_x_magic;   // floor(2^32 / tiles_x) + 1 when tile / tiles_x == umulhi(tile, magic) for every tile, else 0
     int row_mode;             // 1: one row tile (y = row0 + j); 2: tile_rows == 8 == tile height (y = row0 + ty * row_stride + ly); 0: divide
     const uint2 *nodes;       // level-ordered records (vrt_layout.h), root = record 0
@@ -79,7 +79,7 @@ struct KArgs {
     int root0_shift;
     int root0_min[3];         // minimum corner of wide root 0's cube (valid when n_roots > 0)
     int root0_only;           // 1: every record outside wide root 0's subtree is an absent child -- the world is empty outside that cube
-    // Feedback scheduling (SCHED flavours of trace_kernel; vrt_capi.hip owns the buffers). The unit is a GROUP of
+    // Feedback scheduling (SCHED flavours of trace_kernel; vrt_dispatch.cpp owns the buffers). The unit is a GROUP of
     // kGroupTiles consecutive tiles. bit 0: the g-th group of tiles the launch starts is group_order[g] (a permutation
     // of the launch's groups, heaviest first). bit 1: every wave leaves the clock ticks its tile took in
     // tile_cost[tile], from which tile_order_kernel derives the next order.
