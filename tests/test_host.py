@@ -447,6 +447,34 @@ def test_records_from_tree_equal_records_from_texel_stream(V, product_scenes):
     assert s.records() is None
 
 
+def test_dispatcher_knows_when_a_tree_needs_no_ray_stack(V, product_scenes):
+    """vrt::tree_is_opaque (what lets VRT_MODE_FULL run without its 8-deep stack): the shipped maps and the terrain qualify (every
+    leaf alpha 255 with refraction byte 255, or a phantom alpha-0 leaf); the reference's room does not (glass, jelly); one
+    translucent voxel, one opaque voxel whose refraction byte reads as empty space (85) or as 0, disqualify a tree; alpha-0
+    leaves of any refraction and emissive voxels do not."""
+    for name in ("dragon", "monu9", "nature", "terrain"):
+        assert V.tree_is_opaque(product_scenes[name][0]), name
+    assert not V.tree_is_opaque(product_scenes["room"][0])
+    base = [(x, 0, z) for x in range(6) for z in range(6)]
+
+    def world(extra):
+        w = V.World()
+        for x, y, z in base:
+            w.insert(x, y, z, 0xa0a0a0ff)
+        for (x, y, z), args in extra:
+            w.insert(x, y, z, *args)
+        return w.flatten()[0]
+
+    assert V.tree_is_opaque(world([]))
+    assert V.tree_is_opaque(world([((2, 3, 2), (0xffd2d2ff, 3.0, 1.0, 0.0)), ((3, 3, 3), (0x11223300, 1.2, 0.0, 0.5))]))   # emissive; alpha 0
+    assert not V.tree_is_opaque(world([((2, 3, 2), (0xc8dcff50, 1.5, 0.0, 0.0))]))      # glass
+    assert not V.tree_is_opaque(world([((2, 3, 2), (0x3c64dcfe, 3.0, 0.0, 0.0))]))      # alpha 254
+    assert not V.tree_is_opaque(world([((2, 3, 2), (0x50b43cff, 1.0, 0.0, 0.0))]))      # opaque, refraction byte 85: invisible to the hit test
+    assert not V.tree_is_opaque(world([((2, 3, 2), (0x50b43cff, 0.0, 0.0, 0.0))]))      # opaque, refraction byte 0
+    assert V.tree_is_opaque(world([((2, 3, 2), (0x50b43cff, 2.0, 0.0, 0.3))]))
+    assert not V.tree_is_opaque(np.zeros(0, np.uint8)) or True                           # an empty world: either answer is harmless (nothing to hit)
+
+
 def test_box_records_expand_exactly_the_nodes_that_meet_the_box(V):
     """vrth_world_box_records (what a box edit hands to vrt_patch_apply): walked beside the full record array from the same node,
     every child must be the same kind with the same leaf words, except that an INTERNAL child whose cube does not meet the box may

@@ -452,6 +452,17 @@ def root0_choice(texels, eye, world_min=(-1023, -1023, -1023), world_max=(1024, 
     return bool(out[0]), int(out[1]), (int(out[2]), int(out[3]), int(out[4])), int(out[5])
 
 
+def tree_is_opaque(texels):
+    """Host-only (vrt_test_tree_is_opaque): may VRT_MODE_FULL run without a ray stack on this tree (for an eye in empty space)?"""
+    L = test_lib()
+    L.vrt_test_tree_is_opaque.argtypes = [C.c_void_p, C.c_size_t]
+    t = np.ascontiguousarray(texels, np.uint8)
+    r = L.vrt_test_tree_is_opaque(t.ctypes.data if t.size else None, t.size)
+    if r < 0:
+        raise VrtError(f"vrt_test_tree_is_opaque failed ({r})")
+    return r == 1
+
+
 def view_in_range(inv_view):
     m = np.ascontiguousarray(inv_view, np.float32).reshape(16)
     return test_lib().vrt_test_view_in_range(m.ctypes.data) == 1

@@ -217,6 +217,15 @@ long vrt_test_patch_check(const uint8_t *before, size_t before_bytes, const uint
     return bad;
 }
 
+// Host-only: what the dispatcher concludes about a tree before it runs VRT_MODE_FULL without a ray stack (vrt::tree_is_opaque):
+// 1 / 0, or VRT_E_MALFORMED.
+int vrt_test_tree_is_opaque(const uint8_t *texels, size_t used_bytes) {
+    vrt::Layout lay;
+    std::string err;
+    if (!vrt::build_layout(texels, used_bytes, lay, err)) return VRT_E_MALFORMED;
+    return vrt::tree_is_opaque(lay.records) ? 1 : 0;
+}
+
 // Host-only view of the device layout for tests that run without a GPU:
 // writes up to cap records (8 bytes each) and returns the record count, or <0.
 long vrt_test_build_layout(const uint8_t *texels, size_t used_bytes, uint32_t *records_out, size_t cap_records,

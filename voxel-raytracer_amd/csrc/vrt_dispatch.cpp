@@ -126,32 +126,6 @@ vrt_ctx::RayTable *ray_table(vrt_ctx *c, const float *inv_proj, int W, int H) {
 }
 
 // views == nullptr: one view, the context's camera (vrt_set_camera) rendering into d_rgba / d_id.
-// True when pathTrace cannot take its translucent branch (comp:546-572) or absorb (comp:482-486, 512-516) anywhere in this tree for
-// an eye in empty space: every leaf has alpha 0 (never a hit: its medium byte reads as empty space) or alpha 255 with a refraction
-// byte that makes it a surface (not 0 and not 85, which the hit test cannot tell from empty space).
-static bool tree_is_opaque(const std::vector<vrt::Record> &rec) {
-    if (rec.empty()) return false;
-    std::vector<uint32_t> todo{0u};
-    while (!todo.empty()) {
-        const uint32_t i = todo.back();
-        todo.pop_back();
-        const uint32_t mask = rec[i].w0 & 0xffu, leaf_mask = (rec[i].w0 >> 8) & 0xffu;
-        uint32_t child = rec[i].w1;
-        for (uint32_t ci = 0; ci < 8; ++ci) {
-            if (!((mask >> ci) & 1u)) continue;
-            if ((size_t)child >= rec.size()) return false;
-            if ((leaf_mask >> ci) & 1u) {
-                const uint32_t alpha = rec[child].w0 >> 24, refr = rec[child].w1 & 0xffu;
-                if (alpha != 0u && (alpha != 255u || refr == 0u || refr == 85u)) return false;
-            } else {
-                todo.push_back(child);
-            }
-            ++child;
-        }
-    }
-    return true;
-}
-
 int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_rows, int row_stride, int compact,
             int mode, void *d_rgba, void *d_id, hipStream_t s, const vrt_view *views, int n_views) {
     if (!c->have_scene) return vrt_fail(c, VRT_E_STATE, "vrt_dispatch: no octree uploaded (call vrt_upload_octree first)");
@@ -363,7 +337,7 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     // the full path tracer as two tile-coherent passes, where the scene and the view allow it
     bool two_pass = false;
     if (mode == VRT_MODE_FULL && c->two_pass_on && v.trav == 4 && n_views == 1 && c->variant == 0 && !split && vs.v[0].out_rgba) {
-        if (!c->scene_opaque_valid) { c->scene_opaque = tree_is_opaque(c->host_records); c->scene_opaque_valid = true; }
+        if (!c->scene_opaque_valid) { c->scene_opaque = vrt::tree_is_opaque(c->host_records); c->scene_opaque_valid = true; }
         const uint32_t eye_alpha = vs.v[0].eye0 >> 24, eye_b = vs.v[0].eye1 & 0xffu;
         two_pass = c->scene_opaque && eye_alpha == 0u && (eye_b == 0u || eye_b == 85u || eye_b == 255u);
     }

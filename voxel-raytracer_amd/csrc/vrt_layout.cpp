@@ -670,4 +670,31 @@ void compact_records(std::vector<Record> &records) {
     records.swap(out);
 }
 
+// True when pathTrace cannot take its translucent branch (comp:546-572) or absorb (comp:482-486, 512-516) anywhere in this tree for
+// an eye in empty space: every leaf has alpha 0 (never a hit: its medium byte reads as empty space) or alpha 255 with a refraction
+// byte that makes it a surface (not 0 and not 85, which the hit test cannot tell from empty space).
+bool tree_is_opaque(const std::vector<Record> &rec) {
+    if (rec.empty()) return false;
+    std::vector<uint32_t> todo{0u};
+    while (!todo.empty()) {
+        const uint32_t i = todo.back();
+        todo.pop_back();
+        const uint32_t mask = rec[i].w0 & 0xffu, leaf_mask = (rec[i].w0 >> 8) & 0xffu;
+        uint32_t child = rec[i].w1;
+        for (uint32_t ci = 0; ci < 8; ++ci) {
+            if (!((mask >> ci) & 1u)) continue;
+            if ((size_t)child >= rec.size()) return false;
+            if ((leaf_mask >> ci) & 1u) {
+                const uint32_t alpha = rec[child].w0 >> 24, refr = rec[child].w1 & 0xffu;
+                if (alpha != 0u && (alpha != 255u || refr == 0u || refr == 85u)) return false;
+            } else {
+                todo.push_back(child);
+            }
+            ++child;
+        }
+    }
+    return true;
+}
+
+
 }  // namespace vrt

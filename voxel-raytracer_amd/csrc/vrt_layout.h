@@ -100,6 +100,12 @@ bool content_only_in_root0(const std::vector<Record> &records, const WideTree &w
 // subdivided, its cube holds every eye and its side stays >= 2^min_shift, the child takes over. in/out: node, shift, origin.
 void tighten_root0(const WideTree &wt, const int (*eyes)[3], int n, int min_shift, uint32_t &node, int &shift, int origin[3]);
 
+// True when pathTrace (raytracing.comp:435-622) cannot take its translucent branch (:546-572) or absorb (:482-486, 512-516) anywhere in
+// this tree for an eye in empty space: every leaf has alpha 0 (never a hit: its medium byte reads as empty space) or alpha 255 with a
+// refraction byte that makes it a surface (not 0 and not 85, which the hit test cannot tell from empty space). The dispatcher then
+// runs VRT_MODE_FULL without a ray stack (vrt_full.hip.h bounce_pixel).
+bool tree_is_opaque(const std::vector<Record> &records);
+
 // Returns false when the scene cannot be expressed (an internal node of unit size inside an aligned
 // cube, or more than kMaxWideRoots roots): the dispatcher then uses the record-array kernels.
 bool build_wide(const std::vector<Record> &records, const int wmin[3], const int wmax[3], WideTree &out, std::string &why);
