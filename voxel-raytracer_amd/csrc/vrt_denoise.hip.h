@@ -305,7 +305,7 @@ __device__ __forceinline__ void rows_dispatch(const f4 *row, const int rm, const
     }
 }
 
-// One tile (bx, by) by one workgroup of (32 / PX) x TH lanes; s_unorm holds byte / 255.0f. Ends with every lane
+// One tile (bx, by) by one workgroup of (32 / PX) x TH lanes. Ends with every lane
 // past its last LDS read of this tile, but not synchronised.
 // Which rows of the staged window hold a given id at all. A pixel's sum only takes taps that carry its own voxelID -- the pixels of
 // ONE voxel face -- and at the distances where the radius is large a face is a dozen pixels across while the window is 41 x 41:
@@ -325,7 +325,7 @@ struct IdRows {
 __device__ __forceinline__ uint32_t id_slot(const int id) { return ((uint32_t)id * 2654435761u) >> 25; }   // 7 bits
 
 template <int PX, int TH>
-__device__ __forceinline__ void tile(const Args &a, const int bx, const int by, f4 *s_rec, const float *s_unorm, IdRows *s_ids) {
+__device__ __forceinline__ void tile(const Args &a, const int bx, const int by, f4 *s_rec, IdRows *s_ids) {
     constexpr int kTH = TH, kSpanY = TH + 2 * kMaxR;
     constexpr int kLanesX = kTW / PX, kThreads = kLanesX * kTH, kTaps = kSpanX * kSpanY;
     static_assert(kSpanX % PX == 0, "column swizzle");
@@ -416,9 +416,9 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
             const int i = tid + (b + j) * kThreads;
             const int lx = i % kSpanX, ly = i / kSpanX;
             f4 rec;
-            rec.x = s_unorm[col[j] & 0xffu];
-            rec.y = s_unorm[(col[j] >> 8) & 0xffu];
-            rec.z = s_unorm[(col[j] >> 16) & 0xffu];
+            rec.x = unorm_of((float)(col[j] & 0xffu));          // byte / 255.0f, bit for bit (vrt_common.hip.h), without a table in LDS
+            rec.y = unorm_of((float)((col[j] >> 8) & 0xffu));
+            rec.z = unorm_of((float)((col[j] >> 16) & 0xffu));
             rec.w = __int_as_float(vid[j]);
             if (i < kTaps) s_rec[ly * kStride<PX> + slot<PX>(lx)] = rec;
             if (vid[j] != 0 && i < kTaps) {   // fold this tap's row into its id's range, if one of the tile's own pixels carries that id
@@ -526,31 +526,22 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
 }
 
 
-template <int PX, int TH>
-__device__ __forceinline__ void fill_unorm(float *s_unorm) {
-    for (int i = threadIdx.y * (kTW / PX) + threadIdx.x; i < 256; i += kTW / PX * TH) s_unorm[i] = (float)i / 255.0f;
-    __syncthreads();
-}
-
 // One workgroup per tile. waves_per_eu(2, 2) keeps an instance within 256 registers: the default kernel (PX = 2,
 // TH = 16: four waves per workgroup, two workgroups per CU by LDS) needs two waves to share a SIMD. Without it the
 // compiler, seeing occupancy already limited by LDS, spreads into AGPRs and the second workgroup no longer fits.
 template <int PX, int TH, bool SCHED = false>
 __global__ __launch_bounds__(kTW / PX *TH) __attribute__((amdgpu_waves_per_eu(2, 2))) void denoise_px_kernel(const Args a) {
     __shared__ f4 s_rec[kStride<PX> * (TH + 2 * kMaxR)];
-    __shared__ float s_unorm[256];
     __shared__ IdRows s_ids;
     if constexpr (!SCHED) {
-        fill_unorm<PX, TH>(s_unorm);
-        tile<PX, TH>(a, blockIdx.x, blockIdx.y, s_rec, s_unorm, &s_ids);
+        tile<PX, TH>(a, blockIdx.x, blockIdx.y, s_rec, &s_ids);
     } else {  // 1-D grid of whole groups; the tiles of a frame differ by two orders of magnitude (sky: a copy; radius 20: 1,681 taps)
         int t = (int)blockIdx.x;
         if (a.group_order) t = (int)a.group_order[blockIdx.x / kGroupTiles] * kGroupTiles + (int)(blockIdx.x % kGroupTiles);
         if (t >= a.n_tiles) return;
         const unsigned long long t_begin = a.tile_cost ? __builtin_readcyclecounter() : 0ull;
-        fill_unorm<PX, TH>(s_unorm);
         const int by = t / a.tiles_x;
-        tile<PX, TH>(a, t - by * a.tiles_x, by, s_rec, s_unorm, &s_ids);
+        tile<PX, TH>(a, t - by * a.tiles_x, by, s_rec, &s_ids);
         if (a.tile_cost && ((threadIdx.y * (kTW / PX) + threadIdx.x) & 63) == 0)
             atomicMax(&a.tile_cost[t], (uint32_t)(__builtin_readcyclecounter() - t_begin));
     }
