@@ -86,6 +86,9 @@ struct Hit {
     uint32_t r_node, r_anode;
     int r_s, r_as;
     I3 r_last;
+#ifdef VRT_EXP_STATS
+    int iters;        // experiment builds: the march loop's trip count of this lane
+#endif
 };
 
 // The shadow ray's direction-dependent constants (comp:335-345), uniform over a launch: see KArgs::light_inv.
@@ -415,7 +418,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
     const int tiles_x = (a.width + TW - 1) / TW;
     const int tiles_y = (a.n_rows + TH - 1) / TH;
     const int n_tiles = tiles_x * tiles_y;
+#ifndef VRT_EXP_SPLIT
     const int lx = lane % TW, ly = lane / TW;
+#endif
     // One tile per wave and no loop unless PERSIST: without the back edge the kernel arguments need not stay live
     // after ray generation, which is worth ~19 VGPRs (88 -> 69) and two thirds of the SGPR spills on gfx950.
     static_assert(!(PERSIST && SCHED), "the scheduled flavours trace one tile per wave");
@@ -427,6 +432,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
     }
     unsigned long long t_begin = 0;
     if constexpr (SCHED & 2) t_begin = __builtin_readcyclecounter();
+#ifdef VRT_EXP_SPLIT   // experiment builds: every tile as VRT_EXP_SPLIT waves of 64 / VRT_EXP_SPLIT pixels (unscheduled launches only)
+    const int exp_part = first % VRT_EXP_SPLIT;
+    first /= VRT_EXP_SPLIT;
+    if (lane >= 64 / VRT_EXP_SPLIT) return;
+    const int lx = (exp_part * (64 / VRT_EXP_SPLIT) + lane) % TW, ly = (exp_part * (64 / VRT_EXP_SPLIT) + lane) / TW;
+#endif
     for (int tile = first + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
         int tx, ty;
         if (a.tiles_x_magic) {
@@ -484,7 +495,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
             }
         }
         if constexpr (SCHED & 2) {  // the wave has reconverged: this is the time its slowest ray took
+#ifndef VRT_EXP_STATS
             if (lane == 0) a.tile_cost[tile] = (uint32_t)(__builtin_readcyclecounter() - t_begin);
+#endif
         }
         if constexpr (!PERSIST) break;
     }

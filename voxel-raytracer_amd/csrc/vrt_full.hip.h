@@ -242,11 +242,41 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
     const bool shade_fast = a.shade_fast != 0;
     const auto over_pi = [&](float x) { return shade_fast ? div_pi_inrange(x) : x / kPI; };
 
+#ifdef VRT_EXP_STATS   // experiment builds only (tools/room_stats.sh): what the wave's time is made of, left in tile_cost
+    unsigned long long st_acc = 0;
+    const unsigned long long st_begin = __builtin_readcyclecounter();
+#endif
     while (in_regs || sp > 0) {
+#ifdef VRT_EXP_STATS
+        const unsigned long long st_tp = __builtin_readcyclecounter();
+#endif
         if (!in_regs) pop();
         in_regs = false;
         Hit h;
+#ifdef VRT_EXP_STATS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st_t0 = __builtin_readcyclecounter();
+        if (VRT_EXP_STATS == 10) st_acc += st_t0 - st_tp;
+        if (VRT_EXP_STATS == 1) st_acc += 1;
+#endif
         const bool hit = TRAV::march(a, tc_, r.o, r.d, r.iof, iof_to_byte(r.iof), h);
+#ifdef VRT_EXP_STATS
+        if (VRT_EXP_STATS == 2) st_acc += __builtin_readcyclecounter() - st_t0;
+        if (VRT_EXP_STATS == 5) {   // the wave's trips: the longest march of the round
+            int m = h.iters;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(m, off); m = o > m ? o : m; }
+            st_acc += (unsigned long long)m;
+        }
+        if (VRT_EXP_STATS == 6) st_acc += (unsigned long long)h.iters;   // this lane's own trips
+        const unsigned long long st_t2 = __builtin_readcyclecounter();
+        unsigned long long st_t3 = st_t2;
+        // 7: from the end of march() to the translucent / opaque decision (misses end here); 8: the translucent branch; 9: the opaque one
+        // without its shadow ray. Lanes that `continue` out of a segment do not count it: the maximum over lanes is a lane that stayed.
+#define VRT_ST_MARK(k) do { const unsigned long long st_now = __builtin_readcyclecounter(); if (VRT_EXP_STATS == (k)) st_acc += st_now - st_t3; st_t3 = st_now; } while (0)
+#else
+#define VRT_ST_MARK(k) do { } while (0)
+#endif
         float tc[3] = {r.tint[0], r.tint[1], r.tint[2]};
         if (!hit && r.depth <= 0) {
             if (r.dim > 1e-6f && r.md > 0.0f) absorb(tc, r.md, r.dim, r.mc);
@@ -297,6 +327,7 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
             pixel_dist = (int)len3(sub3(hpw, ray_origin));
         }
 
+        VRT_ST_MARK(7);
         if (r.depth <= 0 && sc[3] < 1.0f) {  // translucent, comp:547-572
             const F3 refr_dir = refract3(inc, normal, n1 / n2);
             const float R0 = (n1 - n2) / (n1 + n2) * (n1 - n2) / (n1 + n2);
@@ -326,6 +357,7 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
                 r = make_ray(sub3(hp, scale3(normal, 1e-4f)), refr_dir, n2, r.weight * refract_i, tc, 0.0f, hv.c, hv.c[3] * 5.0f, r.depth);
                 in_regs = true;
             }
+            VRT_ST_MARK(8);
         } else {  // opaque, comp:573-618
             const float emission = hv.p[1] * 10.0f;
             if (emission > 0.0f && r.depth == 0) {
@@ -340,7 +372,15 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
             if (r.depth == 0) {
                 // (the dispatcher's LightSetup, which the primary + shadow kernel takes, costs this one 135 instructions per wave:
                 // at its register budget the uniform values are re-materialised inside the shadow loop)
+                VRT_ST_MARK(9);
+#ifdef VRT_EXP_STATS
+                const unsigned long long st_t1 = __builtin_readcyclecounter();
+#endif
                 const int lit = TRAV::shadow(a, tc_, add3(hp, scale3(normal, 2e-3f)), light, h);
+#ifdef VRT_EXP_STATS
+                if (VRT_EXP_STATS == 3) st_acc += __builtin_readcyclecounter() - st_t1;
+                st_t3 = __builtin_readcyclecounter();
+#endif
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const float direct = gl[k] * (float)lit * ndotl;
@@ -369,8 +409,18 @@ __device__ void trace_pixel_full(const KArgs &a, const View &vw, const typename 
                     in_regs = true;
                 }
             }
+            VRT_ST_MARK(9);
         }
     }
+#ifdef VRT_EXP_STATS
+    if (VRT_EXP_STATS == 4) st_acc = __builtin_readcyclecounter() - st_begin;
+    {
+        uint32_t m = (uint32_t)st_acc;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)m, off); m = o > m ? o : m; }
+        if (a.tile_cost && (px & 7) == 0 && (py & 7) == 0) a.tile_cost[(py >> 3) * ((a.width + 7) >> 3) + (px >> 3)] = m;
+    }
+#endif
     rgba = unorm8(fc[0]) | (unorm8(fc[1]) << 8) | (unorm8(fc[2]) << 16) | (255u << 24);
     idd = make_int2(voxel_id, pixel_dist);
     lo = late_out(late_args(), late_view());

@@ -242,7 +242,7 @@ struct TravT {
     // the ray's own starting medium on the leaving side (comp:318-326).
     template <bool IOF85>
     static VRT_DEV bool march_loop(const KArgs &a, const Ctx &c, F3 &rp, F3 dir, F3 inv, F3 push, I3 dpos, F3 dposf, Walk &w, Found &cur,
-                                   uint32_t iof_byte, int &axis, uint32_t &px, uint32_t &py, I3 &mp, bool forward) {
+                                   uint32_t iof_byte, int &axis, uint32_t &px, uint32_t &py, I3 &mp, bool forward, int *iters = nullptr) {
         Axis ax{false, false};
         F3 pf;
         int i = 0, status = kGo;
@@ -265,6 +265,7 @@ struct TravT {
             go = status != kOutside && !hit && i < 1024;
         } while (go);
         axis = ax.x ? 0 : (ax.yz ? 1 : 2);   // two lane masks merged per iteration by scalar instructions: off the vector port
+        if (iters) *iters = i;
         // the hit flag from the registers the lane left the loop with (IOF85: outside the world `cur` is unchanged, so the
         // bytes are equal)
         asm volatile("" : "+v"(prev_m), "+v"(status));
@@ -324,8 +325,13 @@ struct TravT {
         // one loop per instantiation: choosing between the two per wave (all lanes in refraction 1.0 or not) made the full
         // path tracer hold both and spill 16 registers at its five waves per SIMD
         const bool forward = forward_only(dir);
+#ifdef VRT_EXP_STATS
+        if constexpr (EYE85) hit = march_loop<true>(a, c, rp, dir, inv, push, dpos, dposf, w, cur, iof_byte, axis, px, py, mp, forward, &h.iters);
+        else hit = march_loop<false>(a, c, rp, dir, inv, push, dpos, dposf, w, cur, iof_byte, axis, px, py, mp, forward, &h.iters);
+#else
         if constexpr (EYE85) hit = march_loop<true>(a, c, rp, dir, inv, push, dpos, dposf, w, cur, iof_byte, axis, px, py, mp, forward);
         else hit = march_loop<false>(a, c, rp, dir, inv, push, dpos, dposf, w, cur, iof_byte, axis, px, py, mp, forward);
+#endif
         const float n = -comp(sd, axis);
         h.axis = axis; h.n = n;
         h.map = mp; h.point = rp;
