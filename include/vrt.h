@@ -313,15 +313,23 @@ int vrt_set_tile_scheduling(vrt_ctx *ctx, int period);
  *                          1080p dragon frame; 5, 7: the same built for five / seven waves per SIMD; 1: the two stages as two kernels with
  *                          a 20-byte seed per pixel between them (0.158 ms: the experiment the one-kernel form came from); 0: always the
  *                          general kernel. Scenes with a translucent voxel and eyes inside a medium take the general kernel whatever the
- *                          setting. */
+ *                          setting.
+ *   VRT_OPT_HEAVY_TILES    1 (default): the general VRT_MODE_FULL kernel, on launches the feedback scheduler has an order for, traces the
+ *                          few heaviest groups of tiles (those above 3/4 of the heaviest one's time, when they are at most 32) as eight
+ *                          waves per 8x8 tile instead of one. A frame of a translucent scene is as long as its longest wave -- dozens of
+ *                          rays one after the other, each round as long as the longest of the wave's marches; with 8 pixels per wave that
+ *                          is the longest of 8 instead of 64 (profiles/r03_room_critical_path.txt). 0: every tile is one wave. */
 #define VRT_OPT_RAY_TABLES 1
 #define VRT_OPT_EMPTY_OCTANTS 2
 #define VRT_OPT_DISPLAY_KERNEL 3
 #define VRT_OPT_FULL_OPAQUE 4
+#define VRT_OPT_HEAVY_TILES 5
 int vrt_set_option(vrt_ctx *ctx, int option, int value);
 
 /* The feedback scheduler's order, read and overridden. vrt_get_tile_order copies the current workgroup-group order for the shape last
- * launched on `stream` (NULL: the context's) into out[cap] and returns the number of groups (0 while no order has been derived).
+ * launched on `stream` (NULL: the context's) into out[cap] and returns the number of groups n (0 while no order has been derived);
+ * when cap > n, out[n] receives how many groups at the head of the order VRT_MODE_FULL launches trace as part-tile waves
+ * (VRT_OPT_HEAVY_TILES; 0 for shapes of other modes).
  * vrt_set_tile_order(enable = 1) makes one-view launches of the default kernel take caller-owned DEVICE buffers instead of the
  * scheduler's: d_group_order (a permutation of the launch's groups of four 8x8 tiles, or NULL: row-major) and d_tile_cost (one uint32
  * per tile, receives each tile's clock ticks, or NULL); enable = 0 hands the launches back to the scheduler. Any permutation renders

@@ -833,6 +833,56 @@ def test_multi_gpu_boundary_rehearsed_on_one_device(V, golden, product_scenes):
         V.Multi([0, 99])
 
 
+def test_heaviest_tiles_as_part_tile_waves_never_change_pixels(V, golden, product_scenes):
+    """VRT_OPT_HEAVY_TILES: once the scheduler has an order, the general VRT_MODE_FULL kernel traces the few heaviest groups of tiles as
+    eight waves per tile. The reference's room (the frame is as long as its longest wave there) at four committed frames: every
+    launch -- measuring, ordered, ordered with part-tile waves -- equals the oracle's hashes; the split engages on these frames (its
+    count is read back), and the other modes, the option switched off and an opaque scene under either full kernel keep their pixels."""
+    tex, dim = product_scenes["room"]
+    for key in ("room_inside_1080p_full/mode2", "room_inside_720p_full/mode2", "room_outside_1080p_full/mode2", "room_outside_720p_full/mode2"):
+        g = golden["frames"]["frames"][key]
+        W, H = g["width"], g["height"]
+        for on in (1, 0):
+            c = V.Context(0)
+            try:
+                c.upload_octree(tex, dim)
+                ip, iv, cp, _ = V.camera_block(g["pose"][:3], g["pose"][3], g["pose"][4], W, H)
+                c.set_camera(ip, iv, cp)
+                c.set_tile_scheduling(3)
+                c.set_option(V.OPT_HEAVY_TILES, on)
+                counts = []
+                for k in range(7):
+                    rgba, idd = c.dispatch(W, H, 2)
+                    assert "%016x" % V.fnv1a64(rgba) == g["rgba_fnv1a64"], (key, on, k)
+                    assert "%016x" % V.fnv1a64(idd) == g["id_dist_fnv1a64"], (key, on, k)
+                    counts.append(c.sched_split_count())
+                assert counts[0] == 0 and max(counts) <= 64
+                assert max(counts) > 0, (key, counts)      # the order kernel names heavy groups on these frames
+                g1 = golden["frames"]["frames"].get(key.replace("_full/mode2", "/mode1"))
+                if g1:                                    # a launch of another mode on the same stream never reads them
+                    rgba, idd = c.dispatch(W, H, 1)
+                    assert "%016x" % V.fnv1a64(rgba) == g1["rgba_fnv1a64"]
+            finally:
+                c.close()
+    # an opaque scene: the stack-free kernel has no part-tile waves; the general kernel (FULL_OPAQUE 0) may take them; pixels as committed
+    g = golden["frames"]["frames"]["dragon_720p_full/mode2"]
+    tex, dim = product_scenes["dragon"]
+    c = V.Context(0)
+    try:
+        c.upload_octree(tex, dim)
+        ip, iv, cp, _ = V.camera_block(g["pose"][:3], g["pose"][3], g["pose"][4], g["width"], g["height"])
+        c.set_camera(ip, iv, cp)
+        c.set_tile_scheduling(2)
+        for full_opaque in (6, 0):
+            c.set_option(V.OPT_FULL_OPAQUE, full_opaque)
+            for k in range(5):
+                rgba, idd = c.dispatch(g["width"], g["height"], 2)
+                assert "%016x" % V.fnv1a64(rgba) == g["rgba_fnv1a64"], (full_opaque, k)
+                assert "%016x" % V.fnv1a64(idd) == g["id_dist_fnv1a64"], (full_opaque, k)
+    finally:
+        c.close()
+
+
 def test_feedback_tile_scheduling_never_changes_pixels(V, O, product_scenes):
     """vrt_set_tile_scheduling: launches that repeat a shape start their tiles in an order derived from measured tile
     times. Whatever that order is -- fresh, stale after the camera moved or the scene changed, re-derived on every

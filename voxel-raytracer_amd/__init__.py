@@ -20,7 +20,7 @@ CSRC = os.path.join(HERE, "csrc")
 HIP_LIB = os.environ.get("VRT_HIP_LIB") or os.path.join(HERE, "libvrt_hip.so")   # VRT_HIP_LIB: an A/B build of the same library (tools)
 HOST_LIB = os.path.join(HERE, "libvrt_host.so")
 TEST_LIB = os.path.join(HERE, "libvrt_hip_test.so")   # test support, not product (csrc/test/vrt_test.hip)
-OPT_RAY_TABLES, OPT_EMPTY_OCTANTS, OPT_DISPLAY_KERNEL, OPT_FULL_OPAQUE = 1, 2, 3, 4
+OPT_RAY_TABLES, OPT_EMPTY_OCTANTS, OPT_DISPLAY_KERNEL, OPT_FULL_OPAQUE, OPT_HEAVY_TILES = 1, 2, 3, 4, 5
 
 MODE_PRIMARY, MODE_PRIMARY_SHADOW, MODE_FULL = 0, 1, 2
 MODES = {"primary": MODE_PRIMARY, "primary_shadow": MODE_PRIMARY_SHADOW, "full": MODE_FULL}
@@ -738,6 +738,14 @@ class Context:
         if n < 0:
             self._chk(n)
         return buf[:min(n, cap)].copy()
+
+    def sched_split_count(self, stream=None, cap=1 << 20):
+        """How many groups at the head of the current order a VRT_MODE_FULL launch traces as part-tile waves (OPT_HEAVY_TILES)."""
+        buf = np.zeros(cap, np.uint32)
+        n = self._L.vrt_get_tile_order(self._h, stream, buf.ctypes.data, cap)
+        if n < 0:
+            self._chk(n)
+        return int(buf[n]) if 0 < n < cap else 0
 
     def set_option(self, option, value):
         self._chk(self._L.vrt_set_option(self._h, option, value))

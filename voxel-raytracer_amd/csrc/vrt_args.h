@@ -15,6 +15,9 @@ struct I3 { int x, y, z; };
 // view's first instead of idling the chip between launches.
 constexpr int kMaxViews = 4;
 constexpr int kGroupTiles = 4;  // tiles per scheduling group: 4 adjacent 8x8 tiles, i.e. 32 x 8 pixels
+// The general full path tracer starts the heaviest groups of an ordered launch as kSplitParts waves per tile (one 8-pixel row each):
+// at most kSplitMaxGroups groups (KArgs::split_count, vrt_sched.hip.h)
+constexpr int kSplitParts = 8, kSplitMaxGroups = 64;
 struct View {
     float inv_proj[16];
     float inv_view[16];
@@ -85,6 +88,11 @@ struct KArgs {
     // tile_cost[tile], from which tile_order_kernel derives the next order.
     const uint32_t *group_order;
     uint32_t *tile_cost;
+    // MODE 2 of trace_kernel, ordered launches that do not measure: *split_count = how many groups at the head of group_order are
+    // traced as kSplitParts waves per tile (the order kernel counts the groups above 3/4 of the heaviest one's ticks; 0 when they are
+    // more than kSplitMaxGroups or the heaviest tile does not outlast its even share of the frame -- no tail to shorten). The grid then holds
+    // kSplitMaxGroups * kGroupTiles * (kSplitParts - 1) workgroups more than tiles; the ones no group needs leave at once. null: none.
+    const uint32_t *split_count;
     // Deferred diffuse bounces of the full path tracer (MODE 3 of trace_kernel, vrt_bounce.hip.h): kDeferQueues queues of
     // defer_cap ray records each, structure of arrays (plane p of queue q starts at defer_rec + (p * kDeferQueues + q) * defer_cap),
     // defer_count[q * kDeferStride] = records in queue q, defer_count[(kDeferQueues + q) * kDeferStride] = records already

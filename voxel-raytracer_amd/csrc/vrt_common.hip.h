@@ -418,9 +418,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
     const int tiles_x = (a.width + TW - 1) / TW;
     const int tiles_y = (a.n_rows + TH - 1) / TH;
     const int n_tiles = tiles_x * tiles_y;
-#ifndef VRT_EXP_SPLIT
-    const int lx = lane % TW, ly = lane / TW;
-#endif
+    int lx = lane % TW, ly = lane / TW;
     // One tile per wave and no loop unless PERSIST: without the back edge the kernel arguments need not stay live
     // after ray generation, which is worth ~19 VGPRs (88 -> 69) and two thirds of the SGPR spills on gfx950.
     static_assert(!(PERSIST && SCHED), "the scheduled flavours trace one tile per wave");
@@ -428,16 +426,31 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
     if constexpr (SCHED & 1) {
         static_assert(kGroupTiles % WAVES == 0, "a scheduling group is a whole number of workgroups");
         constexpr int kWgPerGroup = kGroupTiles / WAVES;
-        first = (int)a.group_order[blockIdx.x / kWgPerGroup] * kGroupTiles + (int)(blockIdx.x % kWgPerGroup) * WAVES;
+        // The general full path tracer, ordered launches that do not measure (KArgs::split_count): a frame of a translucent scene is as
+        // long as its longest wave -- 79 rays one after the other behind the glass ball of the reference's room, every round as long
+        // as the longest of the wave's 64 marches (profiles/r03_room_critical_path.txt) -- so the few heaviest groups are traced as
+        // kSplitParts waves per tile, one row of 8 pixels each: the longest of 8 marches instead of 64 per round, 23 % off that wave.
+        constexpr bool kSplit = MODE == 2 && SCHED == 1 && WAVES == 1 && TW == 8;
+        uint32_t wg = blockIdx.x;
+        bool part_wave = false;
+        if constexpr (kSplit) {
+            const uint32_t n_split = a.split_count ? *a.split_count : 0u;
+            constexpr uint32_t kPerGroup = (uint32_t)(kGroupTiles * kSplitParts);
+            if (wg < n_split * kPerGroup) {
+                part_wave = true;
+                first = (int)a.group_order[wg / kPerGroup] * kGroupTiles + (int)((wg % kPerGroup) / (uint32_t)kSplitParts);
+                if (lane >= 64 / kSplitParts) return;
+                lx = lane;
+                ly = (int)(wg % (uint32_t)kSplitParts);
+            } else {
+                wg = wg - n_split * kPerGroup + n_split * (uint32_t)kGroupTiles;   // its place among the whole-tile workgroups
+                if (wg >= (uint32_t)((n_tiles + kGroupTiles - 1) / kGroupTiles * kGroupTiles)) return;   // a workgroup no split group needed
+            }
+        }
+        if (!part_wave) first = (int)a.group_order[wg / kWgPerGroup] * kGroupTiles + (int)(wg % kWgPerGroup) * WAVES;
     }
     unsigned long long t_begin = 0;
     if constexpr (SCHED & 2) t_begin = __builtin_readcyclecounter();
-#ifdef VRT_EXP_SPLIT   // experiment builds: every tile as VRT_EXP_SPLIT waves of 64 / VRT_EXP_SPLIT pixels (unscheduled launches only)
-    const int exp_part = first % VRT_EXP_SPLIT;
-    first /= VRT_EXP_SPLIT;
-    if (lane >= 64 / VRT_EXP_SPLIT) return;
-    const int lx = (exp_part * (64 / VRT_EXP_SPLIT) + lane) % TW, ly = (exp_part * (64 / VRT_EXP_SPLIT) + lane) / TW;
-#endif
     for (int tile = first + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
         int tx, ty;
         if (a.tiles_x_magic) {

@@ -40,7 +40,7 @@ SchedState *sched_state(vrt_ctx *c, hipStream_t s, int width, int n_rows, int ro
     // whole groups of ticks; the words past the last tile are never written and must read as zero
     const size_t cost_bytes = (size_t)n_groups * vrt::kGroupTiles * sizeof(uint32_t);
     if (hipMalloc((void **)&slot->d_cost, cost_bytes) != hipSuccess ||
-        hipMalloc((void **)&slot->d_order, (size_t)n_groups * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&slot->d_order, ((size_t)n_groups + 1) * sizeof(uint32_t)) != hipSuccess ||   // + KArgs::split_count
         hipMemsetAsync(slot->d_cost, 0, cost_bytes, s) != hipSuccess) {
         (void)hipFree(slot->d_cost);
         (void)hipFree(slot->d_order);
@@ -78,7 +78,9 @@ bool measuring_launch(uint64_t launches, int period) {
 int launch_order_kernel(vrt_ctx *c, SchedState *st, hipStream_t s) {
     bool &raised = c->order_lds_raised;   // per context, i.e. per device: the attribute does not carry over to another one
     const bool raise = (size_t)st->n_groups * sizeof(uint32_t) > 48 * 1024 && !raised;
-    VRT_HIP(c, vrt::launch::tile_order(st->d_cost, st->n_groups, st->d_order, raise, (size_t)kSchedMaxGroups * sizeof(uint32_t), s));
+    // the general full path tracer is built for five waves per SIMD; the other states never read the split count
+    const uint32_t wave_slots = st->mode == VRT_MODE_FULL ? (uint32_t)c->n_cus * 4u * 5u : 0u;
+    VRT_HIP(c, vrt::launch::tile_order(st->d_cost, st->n_groups, st->d_order, wave_slots, raise, (size_t)kSchedMaxGroups * sizeof(uint32_t), s));
     if (raise) raised = true;
     st->valid = true;
     return VRT_OK;
@@ -252,6 +254,7 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
         vrt::tighten_root0(c->wide, eyes, n_views, vrt::v3::kAnchorShift, a.root0_node, a.root0_shift, a.root0_min);
     a.group_order = nullptr;
     a.tile_cost = nullptr;
+    a.split_count = nullptr;
     a.defer_rec = nullptr;
     a.defer_count = nullptr;
     a.defer_cap = 0;
@@ -303,6 +306,18 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
     hipError_t e;
     // The full path tracer as two kernels (vrt_bounce.hip.h): the default traversal, one view, a scene with a wide form.
     const bool split = VRT_AB && mode == VRT_MODE_FULL && c->full_split && c->wide_ok && v.trav == 3 && v.block == 64 && n_views == 1 && c->variant == 0;
+    // the full path tracer as two tile-coherent passes, where the scene and the view allow it
+    bool two_pass = false;
+    if (mode == VRT_MODE_FULL && c->two_pass_on && v.trav == 4 && n_views == 1 && c->variant == 0 && !split && vs.v[0].out_rgba) {
+        if (!c->scene_opaque_valid) { c->scene_opaque = vrt::tree_is_opaque(c->host_records); c->scene_opaque_valid = true; }
+        const uint32_t eye_alpha = vs.v[0].eye0 >> 24, eye_b = vs.v[0].eye1 & 0xffu;
+        two_pass = c->scene_opaque && eye_alpha == 0u && (eye_b == 0u || eye_b == 85u || eye_b == 255u);
+    }
+    // the general full path tracer starts the heaviest groups of an ordered, non-measuring launch as part-tile waves (KArgs::split_count)
+    if (mode == VRT_MODE_FULL && !two_pass && !split && st && a.group_order && !a.tile_cost && v.block == 64 && c->heavy_split_on) {
+        a.split_count = st->d_order + st->n_groups;
+        grid += (long)vrt::kSplitMaxGroups * vrt::kGroupTiles * (vrt::kSplitParts - 1);
+    }
     if (split) {
         const size_t cap = (size_t)((tiles + vrt::kDeferQueues - 1) / vrt::kDeferQueues) * 64;   // every pixel of a queue's tiles may defer
         vrt_ctx::DeferQueues *dq = nullptr;
@@ -333,13 +348,6 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
         a.defer_rec = dq->rec;
         a.defer_count = dq->count;
         a.defer_cap = (uint32_t)dq->cap;
-    }
-    // the full path tracer as two tile-coherent passes, where the scene and the view allow it
-    bool two_pass = false;
-    if (mode == VRT_MODE_FULL && c->two_pass_on && v.trav == 4 && n_views == 1 && c->variant == 0 && !split && vs.v[0].out_rgba) {
-        if (!c->scene_opaque_valid) { c->scene_opaque = vrt::tree_is_opaque(c->host_records); c->scene_opaque_valid = true; }
-        const uint32_t eye_alpha = vs.v[0].eye0 >> 24, eye_b = vs.v[0].eye1 & 0xffu;
-        two_pass = c->scene_opaque && eye_alpha == 0u && (eye_b == 0u || eye_b == 85u || eye_b == 255u);
     }
     if (two_pass && c->two_pass_form >= 5) {
         e = vrt::launch::trace_full_opaque(a, vs, (int)grid, c->two_pass_form, s, ev0, ev1);
@@ -608,6 +616,10 @@ int vrt_set_option(vrt_ctx *c, int option, int value) {
             c->two_pass_on = value != 0;
             c->two_pass_form = value;   // 1: two kernels and a seed buffer; 5, 6, 7: both stages in one kernel at that many waves per SIMD
             return VRT_OK;
+        case VRT_OPT_HEAVY_TILES:
+            if (value != 0 && value != 1) break;
+            c->heavy_split_on = value != 0;
+            return VRT_OK;
         case VRT_OPT_DISPLAY_KERNEL:
             if (value == 0 || (value == 1 && VRT_AB)) { c->denoise_variant = value; return VRT_OK; }
             return vrt_fail(c, VRT_E_INVALID, "vrt_set_option: the one-pixel-per-lane display kernel exists in A/B builds only (make AB=1)");
@@ -633,7 +645,7 @@ long vrt_get_tile_order(vrt_ctx *c, void *stream, uint32_t *out, size_t cap) {
     if (!best || !best->valid) return 0;
     VRT_HIP(c, hipSetDevice(c->device));
     VRT_HIP(c, hipStreamSynchronize(best->stream));
-    const size_t n = best->n_groups < cap ? best->n_groups : cap;
+    const size_t n = (size_t)best->n_groups + 1 < cap ? (size_t)best->n_groups + 1 : cap;   // the order, then the split count (KArgs::split_count)
     if (out && n) VRT_HIP(c, hipMemcpy(out, best->d_order, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return (long)best->n_groups;
 }

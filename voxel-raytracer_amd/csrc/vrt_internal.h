@@ -177,6 +177,7 @@ struct vrt_ctx {
     uint64_t ray_tick = 0;
     // VRT_MODE_FULL as two passes (vrt_launch.h trace_full_two_pass): the option, what the uploaded tree allows, the seed buffers
     bool two_pass_on = true;                     // vrt_set_option(VRT_OPT_FULL_OPAQUE)
+    bool heavy_split_on = true;                  // KArgs::split_count (VRT_OPT_HEAVY_TILES)
     int two_pass_form = 6;                       // 6 (default): both stages in one kernel built for six waves per SIMD; 5, 7: for five, seven; 1: two kernels
     bool scene_opaque = false;                   // every leaf has alpha 0, or alpha 255 and a refraction byte that is a surface (not 0 / 85)
     bool scene_opaque_valid = false;

@@ -27,7 +27,8 @@ inline hipError_t trace(int mode, const Variant &v, const KArgs &a, const ViewSe
 // vrt_launch_misc.hip
 // tile_order_kernel: the per-tile ticks of one launch -> the group order of the next ones. raise_lds: set the kernel's dynamic-LDS
 // ceiling first (once per device; needed above 48 KiB).
-hipError_t tile_order(const uint32_t *d_cost, uint32_t n_groups, uint32_t *d_order, bool raise_lds, size_t lds_ceiling, hipStream_t s);
+// wave_slots: waves the chip holds of the kernel the order is for (KArgs::split_count is 0 unless the heaviest tile outlasts its even share); 0: no split count
+hipError_t tile_order(const uint32_t *d_cost, uint32_t n_groups, uint32_t *d_order, uint32_t wave_slots, bool raise_lds, size_t lds_ceiling, hipStream_t s);
 // checks on the device that the kernarg segment is laid out as late_args() / late_view() assume; *d_bad += mismatches
 hipError_t kernarg_probe(const KArgs &a, const ViewSet &vs, uint32_t *d_bad, hipStream_t s);
 

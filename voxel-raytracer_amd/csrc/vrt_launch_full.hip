@@ -9,9 +9,6 @@ hipError_t trace_full(const Variant &v, const KArgs &a, const ViewSet &vs, int g
 #ifndef VRT_FULL_WPE
 #define VRT_FULL_WPE 5
 #endif
-#ifdef VRT_EXP_SPLIT
-    grid *= VRT_EXP_SPLIT;
-#endif
     if (v.trav == 4) return launch_sched<2, v4::TravAny, 8, 64, VRT_FULL_WPE>(a, vs, grid, 0, s, ev0, ev1);
     if (v.trav == 3 && v.block == 64) return launch_sched<2, v3::Trav, 8, 64, 5>(a, vs, grid, 0, s, ev0, ev1);
 #if VRT_AB

@@ -9,13 +9,13 @@
 namespace vrt {
 namespace launch {
 
-hipError_t tile_order(const uint32_t *d_cost, uint32_t n_groups, uint32_t *d_order, bool raise_lds, size_t lds_ceiling, hipStream_t s) {
+hipError_t tile_order(const uint32_t *d_cost, uint32_t n_groups, uint32_t *d_order, uint32_t wave_slots, bool raise_lds, size_t lds_ceiling, hipStream_t s) {
     const size_t lds = (size_t)n_groups * sizeof(uint32_t);
     if (raise_lds) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ceiling);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), lds, s, (const uint4 *)d_cost, n_groups, d_order);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), lds, s, (const uint4 *)d_cost, n_groups, d_order, wave_slots);
     return hipGetLastError();
 }
 

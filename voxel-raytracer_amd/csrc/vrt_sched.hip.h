@@ -10,17 +10,20 @@ namespace vrt {
 // heaviest first, the tail consists of the cheapest tiles instead (longest-processing-time-first list scheduling). A
 // group's cost is the maximum over its kGroupTiles tiles; groups are bucketed by cost (256 linear buckets up to the
 // frame's maximum) and written out from the heaviest bucket down. One workgroup of 1024 lanes; any permutation is
-// correct for the trace kernel, the costs only decide how good it is.
-__global__ __launch_bounds__(1024) void tile_order_kernel(const uint4 *group_ticks, uint32_t n_groups, uint32_t *group_order) {
+// correct for the trace kernel, the costs only decide how good it is. group_order has n_groups + 1 words: the last one is
+// KArgs::split_count.
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint4 *group_ticks, uint32_t n_groups, uint32_t *group_order, uint32_t wave_slots) {
     // group_ticks: the tile_cost words, kGroupTiles per group; the words past the launch's last tile are zero
     static_assert(kGroupTiles == 4, "one 16-byte load per group");
     extern __shared__ uint32_t group_cost[];  // n_groups
-    __shared__ uint32_t hist[256], top;
+    __shared__ uint32_t hist[256], top, n_split;
+    __shared__ unsigned long long all_ticks;
     const uint32_t t = threadIdx.x;
     if (t < 256) hist[t] = 0;
-    if (t == 0) top = 0;
+    if (t == 0) { top = 0; all_ticks = 0ull; }
     __syncthreads();
     uint32_t m = 0;
+    unsigned long long sum = 0ull;
     for (uint32_t base = 0; base < n_groups; base += 8 * 1024) {  // eight loads in flight per lane: one round trip per 8192 groups
         uint4 v[8];
 #pragma unroll
@@ -35,6 +38,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint4 *group_tic
             const uint32_t c = c01 > c23 ? c01 : c23;
             if (g < n_groups) group_cost[g] = c;
             m = c > m ? c : m;
+            sum += (unsigned long long)v[u].x + v[u].y + v[u].z + v[u].w;
         }
     }
 #pragma unroll
@@ -42,7 +46,9 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint4 *group_tic
         const uint32_t v = (uint32_t)__shfl_xor((int)m, off);
         m = v > m ? v : m;
     }
-    if ((t & 63u) == 0u) atomicMax(&top, m);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += (unsigned long long)__shfl_xor((long long)sum, off);
+    if ((t & 63u) == 0u) { atomicMax(&top, m); atomicAdd(&all_ticks, sum); }
     __syncthreads();
     const uint32_t shift = top >= 256 ? 24 - (uint32_t)__builtin_clz(top) : 0;  // top >> shift <= 255
     for (uint32_t g = t; g < n_groups; g += 1024) atomicAdd(&hist[group_cost[g] >> shift], 1u);
@@ -65,6 +71,18 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint4 *group_tic
         hist[4 * t] = above + h3 + h2 + h1;
     }
     __syncthreads();
+    // KArgs::split_count, kept behind the order: the groups in the buckets from 3/4 of the heaviest bucket up are exactly the first
+    // hist[b - 1] of the order (b their lowest bucket). None when they are more than kSplitMaxGroups, and none unless the frame IS
+    // bound by its longest wave: the heaviest tile's ticks against the ticks of all tiles shared out over the chip's wave slots
+    // (the room at 1080p: 1.7 times as long, at 4K 0.5 -- there the part-waves' extra instructions would only cost)
+    if (t == 0) {
+        const uint32_t b = ((top >> shift) * 3u + 3u) / 4u;
+        const uint32_t heavy = b == 0u ? n_groups : hist[b - 1u];
+        const bool tail_bound = wave_slots != 0u && (unsigned long long)top * wave_slots * 4ull > all_ticks * 3ull;   // top > 3/4 of the even share
+        n_split = (top != 0u && tail_bound && heavy <= (uint32_t)kSplitMaxGroups) ? heavy : 0u;
+    }
+    __syncthreads();
+    if (t == 0) group_order[n_groups] = n_split;
     for (uint32_t g = t; g < n_groups; g += 1024) group_order[atomicAdd(&hist[group_cost[g] >> shift], 1u)] = g;
 }
 
