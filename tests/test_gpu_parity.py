@@ -864,6 +864,38 @@ def test_heaviest_tiles_as_part_tile_waves_never_change_pixels(V, golden, produc
                     assert "%016x" % V.fnv1a64(rgba) == g1["rgba_fnv1a64"]
             finally:
                 c.close()
+    # the same frame as two interleaved row shards on two streams (bench.py's pipeline): a scheduler state and a split count per stream
+    # and shard, rows addressed through the shard's own row mapping
+    import torch
+    g = golden["frames"]["frames"]["room_inside_1080p_full/mode2"]
+    W, H = g["width"], g["height"]
+    c = V.Context(0)
+    try:
+        c.upload_octree(tex, dim)
+        ip, iv, cp, _ = V.camera_block(g["pose"][:3], g["pose"][3], g["pose"][4], W, H)
+        c.set_camera(ip, iv, cp)
+        c.set_tile_scheduling(0)
+        full_rgba, full_id = c.dispatch(W, H, 2)
+        assert "%016x" % V.fnv1a64(full_rgba) == g["rgba_fnv1a64"]
+        c.set_tile_scheduling(2)
+        dev = torch.device("cuda:0")
+        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        rows = [V.shard_row_indices(H, 8, s, 2) for s in range(2)]
+        bufs = [(torch.zeros((len(rows[s]), W), dtype=torch.int32, device=dev), torch.zeros((len(rows[s]), W, 2), dtype=torch.int32, device=dev))
+                for s in range(2)]
+        split_seen = 0
+        for k in range(6):
+            for s in range(2):
+                bufs[s][0].zero_(); bufs[s][1].zero_()
+                torch.cuda.synchronize()
+                c.dispatch_shard(W, H, 8, s, 2, 2, bufs[s][0].data_ptr(), bufs[s][1].data_ptr(), streams[s].cuda_stream)
+                torch.cuda.synchronize()
+                assert np.array_equal(bufs[s][0].cpu().numpy().view(np.uint8).reshape(-1, W, 4), full_rgba[rows[s]]), (k, s)
+                assert np.array_equal(bufs[s][1].cpu().numpy(), full_id[rows[s]]), (k, s)
+                split_seen = max(split_seen, c.sched_split_count(streams[s].cuda_stream))
+        assert split_seen > 0
+    finally:
+        c.close()
     # an opaque scene: the stack-free kernel has no part-tile waves; the general kernel (FULL_OPAQUE 0) may take them; pixels as committed
     g = golden["frames"]["frames"]["dragon_720p_full/mode2"]
     tex, dim = product_scenes["dragon"]
