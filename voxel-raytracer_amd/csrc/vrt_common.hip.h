@@ -32,7 +32,7 @@ VRT_DEV F3 normalize3(F3 a) { return scale3(a, 1.0f / __builtin_sqrtf(dot3(a, a)
 // rounded `1.0f / x` and sqrtf(x), WITHOUT their range handling -- the two v_div_scale, v_div_fmas' scale and v_div_fixup;
 // the 2^32 pre-scale, its undo and the zero/infinity class test -- 7 and 9 instructions instead of 12 and 17, and the
 // ones that go are the dear kinds (profiles/r02_valu_rate.txt). Inside the stated ranges those steps are identities, so
-// the results are the same bits (checked against correctly rounded values: vrt_debug_math ops 30 and 31).
+// the results are the same bits (checked against correctly rounded values: vrt_test_math ops 30 and 31, csrc/test/vrt_test.hip).
 //   rcp_inrange : 2^-95 <= |x| < 2^126   (v_div_scale_f32 leaves 1.0 and x alone there)
 //   sqrt_inrange: 2^-96 <= x < infinity
 VRT_DEV float rcp_inrange(float x) {
@@ -51,7 +51,7 @@ VRT_DEV float sqrt_inrange(float x) {
 // the code is compiled -- five fused operations. y is the refined reciprocal the sequence would compute from v_rcp_f32;
 // the sequence's result is the correctly rounded quotient for any starting value within an ulp of 1/d, so the correctly
 // rounded 1/PI serves as one. Below 2^-103 the hardware form rescales and this one may differ in the last bit: such an
-// x is a colour term that rounds to 0 in rgba8 either way. (vrt_debug_math op 32: all 2^23 mantissas and random exponents.)
+// x is a colour term that rounds to 0 in rgba8 either way. (vrt_test_math op 32: all 2^23 mantissas and random exponents.)
 VRT_DEV float div_pi_inrange(float x) {
     constexpr float kD = 3.14159265359f;
     constexpr float kY0 = 0.318309873342514038f;   // 0x3ea2f983 = RN(1 / kD)

@@ -100,7 +100,7 @@ struct vrt_ctx {
     vrt_params params{};
     float inv_proj[16]{}, inv_view[16]{}, cam_pos[4]{};
     int variant = 0;
-    int denoise_variant = 0;  // pixels per lane: 0 -> two, 1 -> one (vrt_debug_set_denoise_variant)
+    int denoise_variant = 0;  // pixels per lane: 0 -> two, 1 -> one (VRT_OPT_DISPLAY_KERNEL)
     // scratch outputs for the host-buffer dispatch
     void *d_rgba = nullptr;
     void *d_id = nullptr;
@@ -148,7 +148,7 @@ struct vrt_ctx {
     size_t cells_capacity = 0;
     // the full path tracer as two kernels (vrt_bounce.hip.h): deferred-bounce queues, sized for the largest launch so far
     bool full_split = false;
-    int bounce_refill_below = 40, bounce_waves_per_simd = 6;   // vrt_debug_set_bounce (tools sweep them)
+    int bounce_refill_below = 40, bounce_waves_per_simd = 6;   // vrt_ab_set_bounce (A/B builds; tools sweep them)
     struct DeferQueues {                  // one set per stream: launches on different streams may overlap
         hipStream_t stream = nullptr;
         float *rec = nullptr;
@@ -184,10 +184,10 @@ struct vrt_ctx {
     struct SeedBuffer { hipStream_t stream = nullptr; uint32_t *d = nullptr; size_t tiles = 0; uint64_t last_use = 0; };
     std::vector<SeedBuffer> seeds;               // one per stream: launches on different streams may overlap
     uint64_t seed_tick = 0;
-    bool tight_root_on = true;                   // vrt_debug_set_root0_only(2 = on without the tighter root)
-    bool root0_only_on = true;                   // vrt_debug_set_root0_only(0): never tell the kernels that the world is empty outside wide root 0
-    bool ray_tables_on = true;                   // vrt_debug_set_ray_tables(0): always the shader's own prologue (A/B, tests)
-    const uint32_t *dbg_group_order = nullptr;  // vrt_debug_set_tile_order: caller-owned buffers instead of the scheduler's
+    bool tight_root_on = true;                   // VRT_OPT_EMPTY_OCTANTS 2 = on without the tighter root
+    bool root0_only_on = true;                   // VRT_OPT_EMPTY_OCTANTS 0: never tell the kernels that the world is empty outside wide root 0
+    bool ray_tables_on = true;                   // VRT_OPT_RAY_TABLES 0: always the shader's own prologue (A/B, tests)
+    const uint32_t *dbg_group_order = nullptr;  // vrt_set_tile_order: caller-owned buffers instead of the scheduler's
     uint32_t *dbg_tile_cost = nullptr;
     bool dbg_sched = false;
     std::string err;
