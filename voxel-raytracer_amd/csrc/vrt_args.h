@@ -88,7 +88,7 @@ struct KArgs {
     // tile_cost[tile], from which tile_order_kernel derives the next order.
     const uint32_t *group_order;
     uint32_t *tile_cost;
-    // MODE 2 of trace_kernel, ordered launches that do not measure: *split_count = how many groups at the head of group_order are
+    // MODE 2 of trace_kernel, launches under an order: *split_count = how many groups at the head of group_order are
     // traced as kSplitParts waves per tile (the order kernel counts the groups above 3/4 of the heaviest one's ticks; 0 when they are
     // more than kSplitMaxGroups or the heaviest tile does not outlast its even share of the frame -- no tail to shorten). The grid then holds
     // kSplitMaxGroups * kGroupTiles * (kSplitParts - 1) workgroups more than tiles; the ones no group needs leave at once. null: none.

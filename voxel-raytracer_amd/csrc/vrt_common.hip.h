@@ -423,6 +423,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
     // after ray generation, which is worth ~19 VGPRs (88 -> 69) and two thirds of the SGPR spills on gfx950.
     static_assert(!(PERSIST && SCHED), "the scheduled flavours trace one tile per wave");
     int first = blockIdx.x * WAVES;  // first tile of this workgroup
+    bool part_wave = false;          // KArgs::split_count: this wave traces one row of its tile
     if constexpr (SCHED & 1) {
         static_assert(kGroupTiles % WAVES == 0, "a scheduling group is a whole number of workgroups");
         constexpr int kWgPerGroup = kGroupTiles / WAVES;
@@ -430,9 +431,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
         // long as its longest wave -- 79 rays one after the other behind the glass ball of the reference's room, every round as long
         // as the longest of the wave's 64 marches (profiles/r03_room_critical_path.txt) -- so the few heaviest groups are traced as
         // kSplitParts waves per tile, one row of 8 pixels each: the longest of 8 marches instead of 64 per round, 23 % off that wave.
-        constexpr bool kSplit = MODE == 2 && SCHED == 1 && WAVES == 1 && TW == 8;
+        constexpr bool kSplit = MODE == 2 && WAVES == 1 && TW == 8;   // SCHED 1 and 3: a measuring launch under an order splits like the others
         uint32_t wg = blockIdx.x;
-        bool part_wave = false;
         if constexpr (kSplit) {
             const uint32_t n_split = a.split_count ? *a.split_count : 0u;
             constexpr uint32_t kPerGroup = (uint32_t)(kGroupTiles * kSplitParts);
@@ -509,7 +509,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
         }
         if constexpr (SCHED & 2) {  // the wave has reconverged: this is the time its slowest ray took
 #ifndef VRT_EXP_STATS
-            if (lane == 0) a.tile_cost[tile] = (uint32_t)(__builtin_readcyclecounter() - t_begin);
+            // a tile traced as part-tile waves reports the longest of them scaled to what the whole tile would have taken (x 21/16: the
+            // room's heaviest row alone is 1.00 ms as whole tiles, 0.77 as eight parts), so that it keeps its place in the next order;
+            // the dispatcher zeroes the ticks before such a launch
+            if (part_wave) { if (lane == 0) atomicMax(&a.tile_cost[tile], (uint32_t)(((__builtin_readcyclecounter() - t_begin) * 21ull) >> 4)); }
+            else if (lane == 0) a.tile_cost[tile] = (uint32_t)(__builtin_readcyclecounter() - t_begin);
 #endif
         }
         if constexpr (!PERSIST) break;

@@ -314,9 +314,11 @@ int enqueue(vrt_ctx *c, int width, int height, int row0, int n_rows, int tile_ro
         two_pass = c->scene_opaque && eye_alpha == 0u && (eye_b == 0u || eye_b == 85u || eye_b == 255u);
     }
     // the general full path tracer starts the heaviest groups of an ordered, non-measuring launch as part-tile waves (KArgs::split_count)
-    if (mode == VRT_MODE_FULL && !two_pass && !split && st && a.group_order && !a.tile_cost && v.block == 64 && c->heavy_split_on) {
+    if (mode == VRT_MODE_FULL && !two_pass && !split && st && a.group_order && v.block == 64 && c->heavy_split_on) {
         a.split_count = st->d_order + st->n_groups;
         grid += (long)vrt::kSplitMaxGroups * vrt::kGroupTiles * (vrt::kSplitParts - 1);
+        // a measuring launch: the part-tile waves of a tile meet in its ticks with atomicMax
+        if (a.tile_cost) VRT_HIP(c, hipMemsetAsync(st->d_cost, 0, (size_t)st->n_groups * vrt::kGroupTiles * sizeof(uint32_t), s));
     }
     if (split) {
         const size_t cap = (size_t)((tiles + vrt::kDeferQueues - 1) / vrt::kDeferQueues) * 64;   // every pixel of a queue's tiles may defer
