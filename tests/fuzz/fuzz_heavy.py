@@ -3,7 +3,7 @@ worlds), VRT_MODE_FULL with the feedback scheduler re-measuring every other laun
 unscheduled frame (same kernel, whole tiles, row-major starts; that frame is held to the oracle by the parity suite)."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import vrt_import
 V = vrt_import.vrt()

@@ -1,12 +1,12 @@
 """One-off parity fuzz on the GPU box (not part of the test suite): random poses in and around the shipped maps,
-all three modes and the display pass, HIP path vs the CPU oracle. usage: tools/fuzz_parity.py [n_poses] [seed]"""
+all three modes and the display pass, HIP path vs the CPU oracle. usage: tests/fuzz/fuzz_parity.py [n_poses] [seed]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import oracle_py as O  # noqa: E402

@@ -3,14 +3,14 @@ test_seeded_random_scenes_uniforms_and_cameras): slabs and clusters of random ma
 refractions, alpha-0 leaves -- placed either around the origin (content in several octants of the world: the general walk)
 or in the positive octant only (the dispatcher's "nothing outside wide root 0" shortcut and its per-launch root), random
 uniforms, eyes outside, beside and INSIDE the material, all three modes against the oracle.
-usage: tools/fuzz_worlds.py [n_worlds] [seed]"""
+usage: tests/fuzz/fuzz_worlds.py [n_worlds] [seed]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import oracle_py as O  # noqa: E402

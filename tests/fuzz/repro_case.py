@@ -1,11 +1,11 @@
-"""One frame of a fuzz case against the oracle, pixel by pixel: tools/repro_case.py map W H x y z yaw pitch [mode]
+"""One frame of a fuzz case against the oracle, pixel by pixel: tests/fuzz/repro_case.py map W H x y z yaw pitch [mode]
 Prints the differing pixels for the default variant with and without the ray-generation tables and for variant 20 (v3)."""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import oracle_py as O  # noqa: E402

@@ -99,3 +99,27 @@ def test_product_never_touches_the_oracle():
                 # comments may SAY "oracle"; no file may include, import, link, load or path into it
                 for needle in ("oracle/", "oracle_py", "liboracle", "oracle.h", "import oracle", "o_render", "o_octree"):
                     assert needle not in text, (base, f, needle)
+
+
+def test_only_the_allowed_callers_run_the_oracle():
+    """Besides tests/, only __graft_entry__.smoke() and bench.py's cpu_baseline leg may import or load anything under oracle/
+    (build() compiles it, which is not using it); the scripts under tools/ and examples/ never do."""
+    import ast
+    for d in ("tools", "examples"):
+        for base, _, files in os.walk(os.path.join(ROOT, d)):
+            for f in files:
+                if f.endswith((".py", ".sh", ".cpp", ".hip", ".h", ".c")):
+                    text = open(os.path.join(base, f), errors="ignore").read()
+                    for needle in ("oracle_py", "liboracle", "oracle.h", "import oracle", '"oracle"', "'oracle'", "o_render", "o_octree", "o_denoise"):
+                        assert needle not in text, (base, f, needle)
+    for name, allowed in (("bench.py", {"cpu_baseline"}), ("__graft_entry__.py", {"smoke", "build"})):
+        tree = ast.parse(open(os.path.join(ROOT, name)).read())
+        for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+            src_names = {getattr(x, "id", None) for x in ast.walk(fn)} | {a.name for x in ast.walk(fn) if isinstance(x, ast.Import) for a in x.names}
+            strings = {x.value for x in ast.walk(fn) if isinstance(x, ast.Constant) and isinstance(x.value, str)}
+            touches = "oracle_py" in src_names or "oracle" in strings or any(s.startswith("oracle/") or "liboracle" in s for s in strings if "\n" not in s and len(s) < 80)
+            if touches:
+                assert fn.name in allowed, (name, fn.name)
+        top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+        assert not any("oracle" in a.name for n in top for a in n.names), name
+

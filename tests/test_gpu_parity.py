@@ -167,7 +167,7 @@ def test_degenerate_inputs(ctx, V, O, product_scenes):
     for pose, (W, H) in [((34.0, 60.0, 34.0, -90.0, 0.0), (64, 36)), ((20.0, 30.0, 20.0, 0.0, 0.0), (40, 40)),
                          ((63.5, 2000.0, 30.5, -90.0, -89.0), (32, 32)),   # camera outside the world (above)
                          ((-2000.5, 50.5, 30.5, 0.0, 0.0), (32, 18)),      # outside, looking in along +x
-                         # outside, the first step lands outside too but within 1024 units of the eye (found by tools/fuzz_parity.py
+                         # outside, the first step lands outside too but within 1024 units of the eye (found by tests/fuzz/fuzz_parity.py
                          # seed 211: the v4 walk took such a point for one of wide root 0)
                          ((877.630258097967, 413.60274114898647, 1499.3121964738943, 32.390759674626054, 37.50787468408298), (47, 53)),
                          ((-919.1504641258679, -530.0652491118379, 1599.2008229520852, -90.0, -45.0), (96, 47)),
@@ -1249,7 +1249,7 @@ def test_rays_leaving_the_only_occupied_cube(ctx, V, O, product_scenes):
              (-200.5, 300.5, 64.5, 0.0, -45.0), (0.0, 40.0, 64.0, 0.0, 0.0), (63.5, 1023.5, 64.5, -90.0, -89.0),
              (64.5, 50.5, 1500.5, -90.0, 0.0), (500.5, -1500.5, 500.5, 45.0, 60.0),
              # eyes INSIDE the model's base, rays leaving the cube through its floor: for them the empty octant below is a
-             # change of medium, i.e. the hit (tools/fuzz_parity.py seed 215)
+             # change of medium, i.e. the hit (tests/fuzz/fuzz_parity.py seed 215)
              (28.89419336319311, 0.16499097268325547, 39.616358418920996, -133.7363734294383, 0.0),
              (14.728327898581782, 4.885433089213199, 24.668633731061217, -40.812579534368126, 45.72688971438939),
              (40.5, 0.5, 45.5, -90.0, -89.0)]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE config 1: custom.vox stand-in, 256x256 frame, single-thread CPU traversal with the host
 library's octree_ray_cast (reference src/octree.cpp:405-485), one call per pixel with the same world direction the
-kernel would use. Prints one JSON line; --check also runs the oracle's restatement and compares every pixel."""
+kernel would use. Prints one JSON line. (Every pixel against the oracle: tests/test_host.py::test_cpu_ray_cast_matches_oracle_config1.)"""
 import argparse
 import json
 import os
@@ -37,7 +37,6 @@ def world_dirs(ip, iv, W, H):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--check", action="store_true")
     args = ap.parse_args()
     V = vrt_import.vrt()
     data = V.make_custom_vox()
@@ -61,22 +60,6 @@ def main():
     out = {"config": "custom.vox stand-in 64^3, 256x256, single-thread CPU octree_ray_cast", "voxels": n,
            "rays": W * H, "hit_fraction": round(float(hit.mean()), 4), "seconds": round(dt, 3),
            "Mrays/s": round(W * H / dt / 1e6, 4), "note": "time includes the Python/ctypes call per ray"}
-    if args.check:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle_py as O
-        t, _, _ = O.load_vox(data)
-        bad = 0
-        for y in range(0, H):
-            for x in range(0, W):
-                d = dirs[y, x]
-                ref = O.lib().o_octree_ray_cast(t, O.Vec3(*pos), O.Vec3(float(d[0]), float(d[1]), float(d[2])),
-                                                O.Vec3(0, 0, 0), O.Vec3(1024, 1024, 1024))
-                if bool(ref) != bool(hit[y, x]):
-                    bad += 1
-                elif ref:
-                    c = ref.contents.voxel.coord
-                    bad += (c.x, c.y, c.z) != tuple(coord[y, x])
-        out["pixels_differing_from_oracle"] = bad
     print(json.dumps(out))
 
 

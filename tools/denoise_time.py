@@ -35,11 +35,15 @@ def main():
     d_id = torch.from_numpy(idd).cuda()
     outs = []
     kinds = ((1, 0), (0, 0), (0, 16)) if len(V.available_variants()) > 5 else ((0, 0), (0, 16))   # the one-pixel kernel: A/B builds only
-    ref = None
-    if os.environ.get("DENOISE_CHECK"):   # against the oracle's quad.frag restatement (slow on big frames)
-        sys.path.insert(0, os.path.join(root, "oracle"))
-        import oracle_py as O
-        ref = O.denoise(rgba, idd)
+    # DENOISE_CHECK: the displayed frame against the oracle's committed hash, where tests/golden/frames.json holds this frame (the oracle
+    # itself is run by tests/ only: tests/test_gpu_parity.py compares the display pass with its quad.frag restatement on rendered and synthetic fields)
+    want = None
+    if os.environ.get("DENOISE_CHECK") and not os.environ.get("DENOISE_SYNTH"):
+        import json
+        for g in json.load(open(os.path.join(root, "tests/golden/frames.json")))["frames"].values():
+            if g.get("map") == name and g.get("width") == W and g.get("height") == H and g.get("mode") == 2 and "shown_fnv1a64" in g and \
+                    "%016x" % V.fnv1a64(rgba) == g["rgba_fnv1a64"]:
+                want = g["shown_fnv1a64"]
     for variant, period in kinds:   # one pixel per lane; two; two with feedback tile scheduling
         ctx.set_denoise_variant(variant)
         ctx.set_tile_scheduling(period)
@@ -59,8 +63,10 @@ def main():
         outs.append(d_out.cpu().numpy())
         print("denoise variant %d scheduling %2d  %s %dx%d  %.4f ms" % (variant, period, name, W, H, e0.elapsed_time(e1) / n))
     print("variants agree:", all(bool(np.array_equal(outs[0], o)) for o in outs[1:]))
-    if ref is not None:
-        print("equal to the oracle:", bool(np.array_equal(outs[-1].view(np.uint8).reshape(H, W, 4), ref)))
+    if want is not None:
+        print("equal to the oracle's committed displayed frame:", "%016x" % V.fnv1a64(outs[-1].view(np.uint8).reshape(H, W, 4)) == want)
+    elif os.environ.get("DENOISE_CHECK"):
+        print("no committed displayed frame for this map / size / pose: kinds compared with each other only")
 
 
 if __name__ == "__main__":
