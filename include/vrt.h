@@ -304,8 +304,11 @@ int vrt_set_tile_scheduling(vrt_ctx *ctx, int period);
  *   VRT_OPT_EMPTY_OCTANTS  1 (default): when the tree is empty outside one aligned cube (every scene loaded at the origin of the
  *                          reference's [-1023,1024)^3 world), rays that leave it end there and the deepest node that still holds
  *                          everything stands in for the root; 2: the same without the tighter root; 0: off (rays walk the empty octants).
- *   VRT_OPT_DISPLAY_KERNEL 0 (default): the display pass sums two pixels per lane; 1: one pixel per lane (round 1's kernel; exists in
- *                          `make AB=1` builds only, VRT_E_INVALID otherwise).
+ *   VRT_OPT_DISPLAY_KERNEL 0 (default): the display pass sums two pixels per lane and every wave takes the cheaper of two walks over its
+ *                          staged window: the rows and column segments any of its 64 lanes needs, the same for all lanes (faces that fill
+ *                          the window: close-ups), or every pixel the box its own voxel face occupies (faces small against the window:
+ *                          1080p dragon frame 0.186 -> 0.142 ms); 2 / 3: always the first / the second walk (A/B, tests); 1: one pixel per
+ *                          lane (round 1's kernel; exists in `make AB=1` builds only, VRT_E_INVALID otherwise).
  *   VRT_OPT_FULL_OPAQUE    VRT_MODE_FULL where pathTrace cannot branch: in a scene without translucent voxels seen from empty space it is
  *                          the primary ray, a shadow ray and ONE diffuse bounce ray that spawns nothing (comp:573-616), so the 8-deep ray
  *                          stack is never used. 6 (default): such launches run a kernel that holds no stack -- primary + shadow stage, then

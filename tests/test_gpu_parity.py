@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 import vrt_import
 
 VARIANTS = vrt_import.vrt().available_variants()   # 0, 1, 4, 20, 22 as shipped; all 25 in a `make AB=1` build
-DISPLAY_KERNELS = (1, 0) if len(VARIANTS) > 5 else (0,)   # the one-pixel-per-lane display kernel of round 1: A/B builds only
+# VRT_OPT_DISPLAY_KERNEL: 0 = two pixels per lane, each wave the cheaper of its two walks (shipped); 2 / 3 = one walk forced (the wave's common
+# rows / every pixel its own box); 1 = the one-pixel-per-lane kernel of round 1, A/B builds only
+DISPLAY_KERNELS = (1, 2, 3, 0) if len(VARIANTS) > 5 else (2, 3, 0)   # the shipped setting last: the shared context keeps it
 
 
 @pytest.fixture(scope="module")

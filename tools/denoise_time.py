@@ -34,7 +34,10 @@ def main():
     d_rgba = torch.from_numpy(rgba.view(np.int32).reshape(H, W)).cuda()
     d_id = torch.from_numpy(idd).cuda()
     outs = []
-    kinds = ((1, 0), (0, 0), (0, 16)) if len(V.available_variants()) > 5 else ((0, 0), (0, 16))   # the one-pixel kernel: A/B builds only
+    # (VRT_OPT_DISPLAY_KERNEL, scheduling period): 1 = one pixel per lane (A/B builds only); 2 / 3 = every wave walks the wave's common
+    # rows / every pixel its own box; 0 = each wave the cheaper of the two (shipped)
+    kinds = ((2, 0), (3, 0), (0, 0), (2, 16), (3, 16), (0, 16))
+    if len(V.available_variants()) > 5: kinds = ((1, 0),) + kinds
     # DENOISE_CHECK: the displayed frame against the oracle's committed hash, where tests/golden/frames.json holds this frame (the oracle
     # itself is run by tests/ only: tests/test_gpu_parity.py compares the display pass with its quad.frag restatement on rendered and synthetic fields)
     want = None

@@ -766,7 +766,7 @@ class Context:
         self._chk(self._L.vrt_ab_set_bounce(self._h, refill_below, waves_per_simd))
 
     def set_denoise_variant(self, v):
-        """Pixels per lane of the display-pass kernel: 0 = two (default), 1 = one (A/B builds only)."""
+        """VRT_OPT_DISPLAY_KERNEL: 0 = two pixels per lane, each wave the cheaper walk (default); 2 / 3 = one walk forced; 1 = one pixel per lane (A/B builds only)."""
         self.set_option(OPT_DISPLAY_KERNEL, v)
 
     def synchronize(self):

@@ -31,6 +31,7 @@ struct Args {
     int tiles_x, n_tiles;
     const uint32_t *group_order;
     uint32_t *tile_cost;   // atomicMax of the waves' clock ticks; zeroed by the host before a measuring launch
+    int rows_path;         // 0: per wave, the cheaper of the two walks below; 2: always the wave's common rows (rows_static); 3: always own boxes (rows_own_box)
 };
 
 __global__ __launch_bounds__(kTile *kTile) void denoise_kernel(const Args a) {
@@ -305,6 +306,46 @@ __device__ __forceinline__ void rows_dispatch(const f4 *row, const int rm, const
     }
 }
 
+// The other walk: every pixel over its OWN box. rows_static walks, for all 64 lanes alike, the rows and column segments that ANY
+// lane of the wave needs -- relative to the lane, so a wave whose pixels sit at all positions inside faces a dozen pixels across
+// needs about twice a face's extent each way. Here a pixel walks the box [cx0, cx0 + w) x [ry0, ry0 + h) of staged taps its id
+// occurs in (the id's first / last staged row and column from the tile's table, cut to the pixel's window), from a per-lane LDS
+// address; the loops run to the largest h and w among the wave's lanes (hmax, wmax: wave-uniform) and a lane masks what lies
+// beyond its own box (such a tap could still carry the id where the box was cut by the window, not by the id's extent). Taps
+// are taken row by row, columns ascending: the shader's order for the taps that carry the id, and the others add +0.
+// Five vector instructions per tap and pixel (two compares, a select, two packed fmas) and an LDS read of its own, against
+// four and half a read in rows_static -- but a 13 x 13 box instead of a 27 x 29 union: where faces are small against the window
+// (radius 15-20 at the distance of the bench poses) that is a third of the instructions. Waves whose faces fill the window
+// (close-ups) keep rows_static: tile() prices both walks per wave. (Measured and not kept: the next trip's reads issued before this
+// trip's sums, 20 % slower -- 64 more live registers at two waves per SIMD; two or eight pairs per trip instead of four, 0-2 % slower.)
+// Column c of a staged row sits in slot (c % 2) * 36 + c / 2: columns c, c + 2, c + 4 ... are consecutive slots, so the walk
+// alternates between two pointers (columns of cx0's parity, and the others).
+template <int PX>
+__device__ __forceinline__ void rows_own_box(const f4 *s_rec, const int cid, const int ry0, const int h, const int cx0, const int w, const int hmax,
+                                             const int wmax, f2 &rg, f2 &bc) {
+    int ia = ry0 * kStride<PX> + slot<PX>(cx0), ib = ry0 * kStride<PX> + slot<PX>(cx0 + 1);
+    const int pairs = (wmax + 1) >> 1;   // wave-uniform
+#pragma unroll 1
+    for (int dy = 0; dy < hmax; ++dy) {
+        const unsigned wv = dy < h ? (unsigned)w : 0u;   // a row below the lane's own box: nothing in range
+        const f4 *pa = s_rec + ia, *pb = s_rec + ib;
+#ifndef VRT_DENOISE_NO_TAPS   // (experiment builds: the pass without its sums, i.e. staging, id table, stores)
+#pragma unroll 1
+        for (int j = 0; j < pairs; j += 4) {   // eight taps per trip, their reads issued together (reads past the box are masked; past
+            f4 ta[4], tb[4];                   // a row's taps they find the row's padding or the next row, staged taps or zeros: finite either way)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ta[i] = pa[j + i]; tb[i] = pb[j + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                tap(ta[i], cid, rg, bc, (unsigned)(2 * (j + i)) < wv);
+                tap(tb[i], cid, rg, bc, (unsigned)(2 * (j + i) + 1) < wv);
+            }
+        }
+#endif
+        if (dy + 1 < h) { ia += kStride<PX>; ib += kStride<PX>; }   // lanes past their last row stay on it (masked)
+    }
+}
+
 // One tile (bx, by) by one workgroup of (32 / PX) x TH lanes. Ends with every lane
 // past its last LDS read of this tile, but not synchronised.
 // Which rows of the staged window hold a given id at all. A pixel's sum only takes taps that carry its own voxelID -- the pixels of
@@ -381,10 +422,22 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
         if (tries == kIdSlots) s_ids->overflow = 1;
     }
     __syncthreads();
-    // stage the 72 x (TH + 40) window: loads of a whole batch are issued before the first is consumed
+    // stage the 72 x (TH + 40) window: loads of a whole batch are issued before the first is consumed. (All sixteen of a thread's
+    // loads requested up front, before its own pixels' -- one round trip per tile instead of three -- measured no faster on the
+    // dragon frame and 30 % slower on the 4K frame, whose sky tiles then load their windows for nothing.)
     const int tx0 = bx * kTW - kMaxR, ty0 = by * kTH - kMaxR;
     constexpr int kBatch = 8;
     constexpr int kStageIters = (kTaps + kThreads * kBatch - 1) / (kThreads * kBatch) * kBatch;
+    // rows_own_box reads up to 23 slots past a lane's box and multiplies what it finds by a zero mask: everything such a read can
+    // reach must hold finite floats -- the eight padding slots behind each row's 72 taps and one row behind the last
+    constexpr int kPad = kStride<PX> - kSpanX;   // 8 with two pixels per lane
+    for (int i = tid; i < kSpanY * kPad + kStride<PX>; i += kThreads) {
+        int at = kSpanY * kStride<PX> + (i - kSpanY * kPad);            // the row behind the window
+        if constexpr (kPad > 0) {
+            if (i < kSpanY * kPad) at = (i / kPad) * kStride<PX> + kSpanX + i % kPad;
+        }
+        s_rec[at] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
     // a thread's taps mostly carry one id after another (its taps lie 3.5 rows apart in one column band): runs of one id are folded
     // in registers and reach the table once per run -- on a close-up where one face fills the tile that is two atomics per thread
     // instead of two per tap on ONE slot
@@ -502,8 +555,48 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
         uint32_t seg_mask = 0u;
         for (int sg = 0; sg * kSeg < 2 * rm + PX; ++sg)
             if (sg * kSeg <= u_last && sg * kSeg + kSeg - 1 >= u_first) seg_mask |= 1u << sg;
+        // every pixel's own box (rows_own_box) and what the wave's loops over them would cost against the common rows
+        bool own = false;
+        if (!s_ids->overflow && a.rows_path != 2) {
+            int ry0[PX], bh[PX], cx0[PX], bw[PX], hmax[PX], wmax[PX];
+            int cost_own = 0;
+#pragma unroll
+            for (int k = 0; k < PX; ++k) {
+                ry0[k] = cx0[k] = 0;
+                bh[k] = bw[k] = 0;
+                if (cid[k] != 0) {
+                    uint32_t sl = id_slot(cid[k]);
+                    while (s_ids->id[sl] != cid[k]) sl = (sl + 1u) & (kIdSlots - 1);
+                    const int row_s = (int)threadIdx.y + kMaxR, col_s = kMaxR + (int)threadIdx.x * PX + k;
+                    const int r0 = s_ids->lo[sl] > row_s - R[k] ? s_ids->lo[sl] : row_s - R[k];
+                    const int r1 = s_ids->hi[sl] < row_s + R[k] ? s_ids->hi[sl] : row_s + R[k];
+                    const int c0 = s_ids->xlo[sl] > col_s - R[k] ? s_ids->xlo[sl] : col_s - R[k];
+                    const int c1 = s_ids->xhi[sl] < col_s + R[k] ? s_ids->xhi[sl] : col_s + R[k];
+                    ry0[k] = r0; bh[k] = r1 - r0 + 1;    // the pixel itself carries the id: both at least 1
+                    cx0[k] = c0; bw[k] = c1 - c0 + 1;
+                }
+                hmax[k] = bh[k]; wmax[k] = bw[k];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const int hh = __shfl_xor(hmax[k], off), ww = __shfl_xor(wmax[k], off);
+                    hmax[k] = hh > hmax[k] ? hh : hmax[k];
+                    wmax[k] = ww > wmax[k] ? ww : wmax[k];
+                }
+                hmax[k] = __builtin_amdgcn_readfirstlane(hmax[k]);
+                wmax[k] = __builtin_amdgcn_readfirstlane(wmax[k]);
+                cost_own += hmax[k] * (((wmax[k] + 7) & ~7) * 5 + 8);
+            }
+            const int cost_common = (y_last - y_first + 1) * (__builtin_popcount(seg_mask) * kSeg * 4 * PX + 4);
+            own = a.rows_path == 3 || cost_own * 9 < cost_common * 8;
+            if (own) {
+#pragma unroll
+                for (int k = 0; k < PX; ++k)
+                    if (hmax[k] != 0) rows_own_box<PX>(s_rec, cid[k], ry0[k], bh[k], cx0[k], bw[k], hmax[k], wmax[k], acc.rg[k], acc.bc[k]);
+            }
+        }
         const f4 *row = s_rec + (threadIdx.y + kMaxR - rm) * kStride<PX> + threadIdx.x;  // window row -rm, lane column base
-        if (delta == 0)
+        if (own) {
+        } else if (delta == 0)
             rows_dispatch<PX, 0>(row, rm, cid, R, acc, y_first, y_last, seg_mask);
         else if (delta == 1)
             rows_dispatch<PX, 1>(row, rm, cid, R, acc, y_first, y_last, seg_mask);
@@ -531,7 +624,7 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
 // compiler, seeing occupancy already limited by LDS, spreads into AGPRs and the second workgroup no longer fits.
 template <int PX, int TH, bool SCHED = false>
 __global__ __launch_bounds__(kTW / PX *TH) __attribute__((amdgpu_waves_per_eu(2, 2))) void denoise_px_kernel(const Args a) {
-    __shared__ f4 s_rec[kStride<PX> * (TH + 2 * kMaxR)];
+    __shared__ f4 s_rec[kStride<PX> * (TH + 2 * kMaxR + 1)];   // + one row of zeros behind the window (rows_own_box reads past its boxes)
     __shared__ IdRows s_ids;
     if constexpr (!SCHED) {
         tile<PX, TH>(a, blockIdx.x, blockIdx.y, s_rec, &s_ids);

@@ -623,7 +623,7 @@ int vrt_set_option(vrt_ctx *c, int option, int value) {
             c->heavy_split_on = value != 0;
             return VRT_OK;
         case VRT_OPT_DISPLAY_KERNEL:
-            if (value == 0 || (value == 1 && VRT_AB)) { c->denoise_variant = value; return VRT_OK; }
+            if (value == 0 || value == 2 || value == 3 || (value == 1 && VRT_AB)) { c->denoise_variant = value; return VRT_OK; }
             return vrt_fail(c, VRT_E_INVALID, "vrt_set_option: the one-pixel-per-lane display kernel exists in A/B builds only (make AB=1)");
         default:
             return vrt_fail(c, VRT_E_INVALID, "vrt_set_option: unknown option");

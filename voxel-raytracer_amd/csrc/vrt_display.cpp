@@ -17,6 +17,7 @@ int vrt_denoise(vrt_ctx *c, int width, int height, const void *d_rgba8, const vo
     if (!d_rgba8 || !d_id_dist || !d_out_rgba8 || d_rgba8 == d_out_rgba8) return vrt_fail(c, VRT_E_INVALID, "vrt_denoise: null or aliased buffers");
     VRT_HIP(c, hipSetDevice(c->device));
     vrt::launch::Denoise d{d_rgba8, d_id_dist, d_out_rgba8, width, height, nullptr, nullptr};
+    d.rows_path = c->denoise_variant >= 2 ? c->denoise_variant : 0;
     const hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     if (c->denoise_variant == 1) {
         VRT_HIP(c, vrt::launch::denoise(d, 1, false, s));
@@ -27,7 +28,7 @@ int vrt_denoise(vrt_ctx *c, int width, int height, const void *d_rgba8, const vo
     vrt::launch::denoise_tiling(width, height, tiles_x, n_tiles);
     const long groups = ((long)n_tiles + vrt::kGroupTiles - 1) / vrt::kGroupTiles;
     SchedState *st = nullptr;
-    if (c->sched_period > 0 && groups >= kSchedMinDenoiseGroups && groups <= kSchedMaxGroups)
+    if (c->sched_period > 0 && groups >= kSchedMinDenoiseGroups && groups <= kSchedMaxDenoiseGroups)
         st = sched_state(c, s, width, height, 0, 0, 0, kSchedDenoise, (uint32_t)n_tiles, (uint32_t)groups);
     if (!st) {
         VRT_HIP(c, vrt::launch::denoise(d, 0, false, s));

@@ -41,6 +41,7 @@ struct Denoise {
     int width, height;
     const uint32_t *group_order;
     uint32_t *tile_cost;
+    int rows_path = 0;   // denoise::Args::rows_path
 };
 void denoise_tiling(int width, int height, int &tiles_x, int &n_tiles);
 hipError_t denoise(const Denoise &d, int variant, bool whole_groups, hipStream_t s);

@@ -40,6 +40,7 @@ hipError_t denoise(const Denoise &d, int variant, bool whole_groups, hipStream_t
     denoise_tiling(d.width, d.height, a.tiles_x, a.n_tiles);
     a.group_order = d.group_order;
     a.tile_cost = d.tile_cost;
+    a.rows_path = d.rows_path;
     if (variant == 1) {
 #if VRT_AB
         const dim3 grid((unsigned)((d.width + kTile - 1) / kTile), (unsigned)((d.height + kTile - 1) / kTile));
