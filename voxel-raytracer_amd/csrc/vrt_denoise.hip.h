@@ -320,30 +320,57 @@ __device__ __forceinline__ void rows_dispatch(const f4 *row, const int rm, const
 // trip's sums, 20 % slower -- 64 more live registers at two waves per SIMD; two or eight pairs per trip instead of four, 0-2 % slower.)
 // Column c of a staged row sits in slot (c % 2) * 36 + c / 2: columns c, c + 2, c + 4 ... are consecutive slots, so the walk
 // alternates between two pointers (columns of cx0's parity, and the others).
+// The lane's PX pixels are walked at once: one loop nest to the largest box among all of them, PX independent chains of sums and PX times
+// the reads in flight per trip (the pass runs two waves per SIMD: what hides an LDS read's latency is the lane's own other work; one
+// pixel after the other measured 6 % slower). Eight taps per pixel and trip, their reads issued together: reads past a box are masked;
+// past a row's taps they find the row's padding or the next row, staged taps or zeros: finite either way (tile() zeroes the padding).
+typedef const f4 __attribute__((address_space(3))) *LdsF4;   // a pointer typed as LDS: a function that is not inlined must not depend on the compiler proving it (a flat pointer is read with flat loads)
 template <int PX>
-__device__ __forceinline__ void rows_own_box(const f4 *s_rec, const int cid, const int ry0, const int h, const int cx0, const int w, const int hmax,
-                                             const int wmax, f2 &rg, f2 &bc) {
-    int ia = ry0 * kStride<PX> + slot<PX>(cx0), ib = ry0 * kStride<PX> + slot<PX>(cx0 + 1);
+struct Boxes {   // per lane: its pixels' ids and the boxes they occur in (staged rows / columns; h = w = 0: a pixel that is not summed)
+    int cid[PX], ry0[PX], h[PX], cx0[PX], w[PX];
+};
+// Not inlined, by value in and out: rows_static's instances fill the register file by design (a whole row's reads hoisted), and with this
+// walk inlined beside them every one of them spilled a dozen registers (the common-rows walk of a close-up frame: 0.51 -> 0.92 ms).
+template <int PX>
+__device__ __attribute__((noinline)) Acc<PX> rows_own_box(const LdsF4 s_rec, const Boxes<PX> b, const int hmax_, const int wmax_) {
+    // arguments of a function that is not inlined arrive in vector registers: the loop bounds are wave-uniform, say so
+    const int hmax = __builtin_amdgcn_readfirstlane(hmax_), wmax = __builtin_amdgcn_readfirstlane(wmax_);
+    const int (&cid)[PX] = b.cid, (&ry0)[PX] = b.ry0, (&h)[PX] = b.h, (&cx0)[PX] = b.cx0, (&w)[PX] = b.w;
+    Acc<PX> acc;
+#pragma unroll
+    for (int k = 0; k < PX; ++k) { acc.rg[k] = f2{0.0f, 0.0f}; acc.bc[k] = f2{0.0f, 0.0f}; }
+    int ia[PX], ib[PX];
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+        ia[k] = ry0[k] * kStride<PX> + slot<PX>(cx0[k]);
+        ib[k] = ry0[k] * kStride<PX> + slot<PX>(cx0[k] + 1);
+    }
     const int pairs = (wmax + 1) >> 1;   // wave-uniform
 #pragma unroll 1
     for (int dy = 0; dy < hmax; ++dy) {
-        const unsigned wv = dy < h ? (unsigned)w : 0u;   // a row below the lane's own box: nothing in range
-        const f4 *pa = s_rec + ia, *pb = s_rec + ib;
-#ifndef VRT_DENOISE_NO_TAPS   // (experiment builds: the pass without its sums, i.e. staging, id table, stores)
+        unsigned wv[PX];
+#pragma unroll
+        for (int k = 0; k < PX; ++k) wv[k] = dy < h[k] ? (unsigned)w[k] : 0u;
 #pragma unroll 1
-        for (int j = 0; j < pairs; j += 4) {   // eight taps per trip, their reads issued together (reads past the box are masked; past
-            f4 ta[4], tb[4];                   // a row's taps they find the row's padding or the next row, staged taps or zeros: finite either way)
+        for (int j = 0; j < pairs; j += 4) {
+            f4 ta[PX][4], tb[PX][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { ta[i] = pa[j + i]; tb[i] = pb[j + i]; }
+            for (int k = 0; k < PX; ++k)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                tap(ta[i], cid, rg, bc, (unsigned)(2 * (j + i)) < wv);
-                tap(tb[i], cid, rg, bc, (unsigned)(2 * (j + i) + 1) < wv);
-            }
+                for (int i = 0; i < 4; ++i) { ta[k][i] = s_rec[ia[k] + j + i]; tb[k][i] = s_rec[ib[k] + j + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < PX; ++k) {
+                    tap(ta[k][i], cid[k], acc.rg[k], acc.bc[k], (unsigned)(2 * (j + i)) < wv[k]);
+                    tap(tb[k][i], cid[k], acc.rg[k], acc.bc[k], (unsigned)(2 * (j + i) + 1) < wv[k]);
+                }
         }
-#endif
-        if (dy + 1 < h) { ia += kStride<PX>; ib += kStride<PX>; }   // lanes past their last row stay on it (masked)
+#pragma unroll
+        for (int k = 0; k < PX; ++k)
+            if (dy + 1 < h[k]) { ia[k] += kStride<PX>; ib[k] += kStride<PX>; }
     }
+    return acc;
 }
 
 // One tile (bx, by) by one workgroup of (32 / PX) x TH lanes. Ends with every lane
@@ -448,6 +475,68 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
             atomicMin(&s_ids->xlo[run_slot], run_xlo); atomicMax(&s_ids->xhi[run_slot], run_xhi);
         }
     };
+    const auto stage_tap = [&](const int vidj, const uint32_t colj, const int lx, const int ly) {
+        f4 rec;
+        rec.x = unorm_of((float)(colj & 0xffu));          // byte / 255.0f, bit for bit (vrt_common.hip.h), without a table in LDS
+        rec.y = unorm_of((float)((colj >> 8) & 0xffu));
+        rec.z = unorm_of((float)((colj >> 16) & 0xffu));
+        rec.w = __int_as_float(vidj);
+        s_rec[ly * kStride<PX> + slot<PX>(lx)] = rec;
+        if (vidj != 0) {   // fold this tap's row and column into its id's ranges, if one of the tile's own pixels carries that id
+            if (vidj == run_id) {
+                run_lo = ly < run_lo ? ly : run_lo;
+                run_hi = ly > run_hi ? ly : run_hi;
+                run_xlo = lx < run_xlo ? lx : run_xlo;
+                run_xhi = lx > run_xhi ? lx : run_xhi;
+            } else {
+                flush_run();
+                run_id = vidj;
+                run_slot = -1;
+                run_lo = run_hi = ly;
+                run_xlo = run_xhi = lx;
+                uint32_t sl = id_slot(vidj);
+                for (int tries = 0; tries < kIdSlots; ++tries, sl = (sl + 1u) & (kIdSlots - 1)) {
+                    const int at = s_ids->id[sl];
+                    if (at == vidj) { run_slot = (int)sl; break; }
+                    if (at == 0) break;
+                }
+            }
+        }
+    };
+    // Four consecutive taps of a row per thread and step where the images allow 16-byte loads (the width a multiple of four, the
+    // pointers aligned: tx0 and the 72-tap rows are multiples of four, so a quad lies wholly inside or outside the image): one
+    // 16-byte load for four colours, two for four (voxelID, dist) pairs -- 12 loads per thread instead of 32 -- and four taps that mostly
+    // carry ONE id, so the id table sees one run per quad instead of one per tap (its atomics were a fifth of the pass without its sums).
+    constexpr int kQuads = kTaps / 4, kQuadIters = (kQuads + kThreads - 1) / kThreads;
+    static_assert(kSpanX % 4 == 0 && kTW % 4 == 0 && kMaxR % 4 == 0, "quads never straddle a row or the image's edge");
+    const bool quads = (a.width & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.rgba) | reinterpret_cast<uintptr_t>(a.id)) & 15u) == 0u;   // uniform
+    if (quads) {
+        uint4 cq[kQuadIters], iq0[kQuadIters], iq1[kQuadIters];
+#pragma unroll
+        for (int q = 0; q < kQuadIters; ++q) {
+            const int i4 = tid + q * kThreads;
+            const int lx = (i4 % (kSpanX / 4)) * 4, ly = i4 / (kSpanX / 4);
+            const int gx = tx0 + lx, gy = ty0 + ly;
+            cq[q] = iq0[q] = iq1[q] = make_uint4(0u, 0u, 0u, 0u);
+            if (i4 < kQuads && gx >= 0 && gx < a.width && gy >= 0 && gy < a.height) {
+                const size_t g = (size_t)gy * (size_t)a.width + (size_t)gx;
+                cq[q] = *reinterpret_cast<const uint4 *>(a.rgba + g);
+                iq0[q] = *reinterpret_cast<const uint4 *>(a.id + g);        // (id, dist) of pixels g, g + 1
+                iq1[q] = *reinterpret_cast<const uint4 *>(a.id + g + 2);    // ... g + 2, g + 3
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kQuadIters; ++q) {
+            const int i4 = tid + q * kThreads;
+            if (i4 < kQuads) {
+                const int lx = (i4 % (kSpanX / 4)) * 4, ly = i4 / (kSpanX / 4);
+                stage_tap((int)iq0[q].x, cq[q].x, lx, ly);
+                stage_tap((int)iq0[q].z, cq[q].y, lx + 1, ly);
+                stage_tap((int)iq1[q].x, cq[q].z, lx + 2, ly);
+                stage_tap((int)iq1[q].z, cq[q].w, lx + 3, ly);
+            }
+        }
+    } else
     for (int b = 0; b < kStageIters; b += kBatch) {
         int vid[kBatch];
         uint32_t col[kBatch];
@@ -467,33 +556,7 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
             const int i = tid + (b + j) * kThreads;
-            const int lx = i % kSpanX, ly = i / kSpanX;
-            f4 rec;
-            rec.x = unorm_of((float)(col[j] & 0xffu));          // byte / 255.0f, bit for bit (vrt_common.hip.h), without a table in LDS
-            rec.y = unorm_of((float)((col[j] >> 8) & 0xffu));
-            rec.z = unorm_of((float)((col[j] >> 16) & 0xffu));
-            rec.w = __int_as_float(vid[j]);
-            if (i < kTaps) s_rec[ly * kStride<PX> + slot<PX>(lx)] = rec;
-            if (vid[j] != 0 && i < kTaps) {   // fold this tap's row into its id's range, if one of the tile's own pixels carries that id
-                if (vid[j] == run_id) {
-                    run_lo = ly < run_lo ? ly : run_lo;
-                    run_hi = ly > run_hi ? ly : run_hi;
-                    run_xlo = lx < run_xlo ? lx : run_xlo;
-                    run_xhi = lx > run_xhi ? lx : run_xhi;
-                } else {
-                    flush_run();
-                    run_id = vid[j];
-                    run_slot = -1;
-                    run_lo = run_hi = ly;
-                    run_xlo = run_xhi = lx;
-                    uint32_t sl = id_slot(vid[j]);
-                    for (int tries = 0; tries < kIdSlots; ++tries, sl = (sl + 1u) & (kIdSlots - 1)) {
-                        const int at = s_ids->id[sl];
-                        if (at == vid[j]) { run_slot = (int)sl; break; }
-                        if (at == 0) break;
-                    }
-                }
-            }
+            if (i < kTaps) stage_tap(vid[j], col[j], i % kSpanX, i / kSpanX);
         }
     }
     flush_run();
@@ -558,12 +621,12 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
         // every pixel's own box (rows_own_box) and what the wave's loops over them would cost against the common rows
         bool own = false;
         if (!s_ids->overflow && a.rows_path != 2) {
-            int ry0[PX], bh[PX], cx0[PX], bw[PX], hmax[PX], wmax[PX];
-            int cost_own = 0;
+            Boxes<PX> bx_;
+            int hm = 0, wm = 0;   // the largest box among the lane's pixels, then among the wave's lanes
 #pragma unroll
             for (int k = 0; k < PX; ++k) {
-                ry0[k] = cx0[k] = 0;
-                bh[k] = bw[k] = 0;
+                bx_.cid[k] = cid[k]; bx_.ry0[k] = bx_.cx0[k] = 0;
+                bx_.h[k] = bx_.w[k] = 0;
                 if (cid[k] != 0) {
                     uint32_t sl = id_slot(cid[k]);
                     while (s_ids->id[sl] != cid[k]) sl = (sl + 1u) & (kIdSlots - 1);
@@ -572,26 +635,25 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
                     const int r1 = s_ids->hi[sl] < row_s + R[k] ? s_ids->hi[sl] : row_s + R[k];
                     const int c0 = s_ids->xlo[sl] > col_s - R[k] ? s_ids->xlo[sl] : col_s - R[k];
                     const int c1 = s_ids->xhi[sl] < col_s + R[k] ? s_ids->xhi[sl] : col_s + R[k];
-                    ry0[k] = r0; bh[k] = r1 - r0 + 1;    // the pixel itself carries the id: both at least 1
-                    cx0[k] = c0; bw[k] = c1 - c0 + 1;
+                    bx_.ry0[k] = r0; bx_.h[k] = r1 - r0 + 1;    // the pixel itself carries the id: both at least 1
+                    bx_.cx0[k] = c0; bx_.w[k] = c1 - c0 + 1;
                 }
-                hmax[k] = bh[k]; wmax[k] = bw[k];
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) {
-                    const int hh = __shfl_xor(hmax[k], off), ww = __shfl_xor(wmax[k], off);
-                    hmax[k] = hh > hmax[k] ? hh : hmax[k];
-                    wmax[k] = ww > wmax[k] ? ww : wmax[k];
-                }
-                hmax[k] = __builtin_amdgcn_readfirstlane(hmax[k]);
-                wmax[k] = __builtin_amdgcn_readfirstlane(wmax[k]);
-                cost_own += hmax[k] * (((wmax[k] + 7) & ~7) * 5 + 8);
+                hm = bx_.h[k] > hm ? bx_.h[k] : hm;
+                wm = bx_.w[k] > wm ? bx_.w[k] : wm;
             }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const int hh = __shfl_xor(hm, off), ww = __shfl_xor(wm, off);
+                hm = hh > hm ? hh : hm;
+                wm = ww > wm ? ww : wm;
+            }
+            hm = __builtin_amdgcn_readfirstlane(hm);
+            wm = __builtin_amdgcn_readfirstlane(wm);
+            const int cost_own = hm * (((wm + 7) & ~7) * 5 * PX + 8);
             const int cost_common = (y_last - y_first + 1) * (__builtin_popcount(seg_mask) * kSeg * 4 * PX + 4);
             own = a.rows_path == 3 || cost_own * 9 < cost_common * 8;
             if (own) {
-#pragma unroll
-                for (int k = 0; k < PX; ++k)
-                    if (hmax[k] != 0) rows_own_box<PX>(s_rec, cid[k], ry0[k], bh[k], cx0[k], bw[k], hmax[k], wmax[k], acc.rg[k], acc.bc[k]);
+                acc = rows_own_box<PX>((LdsF4)s_rec, bx_, hm, wm);
             }
         }
         const f4 *row = s_rec + (threadIdx.y + kMaxR - rm) * kStride<PX> + threadIdx.x;  // window row -rm, lane column base
