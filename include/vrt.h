@@ -307,7 +307,7 @@ int vrt_set_tile_scheduling(vrt_ctx *ctx, int period);
  *   VRT_OPT_DISPLAY_KERNEL 0 (default): the display pass sums two pixels per lane and every wave takes the cheaper of two walks over its
  *                          staged window: the rows and column segments any of its 64 lanes needs, the same for all lanes (faces that fill
  *                          the window: close-ups), or every pixel the box its own voxel face occupies (faces small against the window:
- *                          1080p dragon frame 0.186 -> 0.142 ms); 2 / 3: always the first / the second walk (A/B, tests); 1: one pixel per
+ *                          1080p dragon frame 0.186 -> 0.123 ms with the staging changes that came with it); 2 / 3: always the first / the second walk (A/B, tests); 1: one pixel per
  *                          lane (round 1's kernel; exists in `make AB=1` builds only, VRT_E_INVALID otherwise).
  *   VRT_OPT_FULL_OPAQUE    VRT_MODE_FULL where pathTrace cannot branch: in a scene without translucent voxels seen from empty space it is
  *                          the primary ray, a shadow ray and ONE diffuse bounce ray that spawns nothing (comp:573-616), so the 8-deep ray

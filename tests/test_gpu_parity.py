@@ -350,23 +350,24 @@ def test_denoise_pass_matches_quad_frag_restatement(ctx, V, O, product_scenes):
     # the per-id row / column table of the tile (IdRows, 128 slots): every pixel its own id (the table overflows: whole windows),
     # ~100 ids per tile (long probe chains), ids that all hash to ONE slot, an id whose pixels lie far apart inside a window (the
     # walked rows and column segments are the union), ids that appear only in a tile's halo
-    W, H = 131, 83
-    yy, xx = np.mgrid[0:H, 0:W]
-    slot = lambda v: ((int(v) * 2654435761) & 0xffffffff) >> 25
-    same_slot = [v for v in range(1, 400000) if slot(v) == 5][:40]
-    fields = [1 + yy * W + xx, 1 + (yy // 2) * 16 + (xx // 3) % 16 + 1000 * (xx // 48), np.array(same_slot)[(yy // 4 * 7 + xx // 5) % 40],
-              np.where((xx % 37 < 2) | (yy % 29 < 2), 9, 1 + (xx // 9 + 11 * (yy // 7)) % 60), np.where(xx % 32 < 20, 0, 3 + yy // 6)]
-    for k, ids in enumerate(fields):
-        rgba = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8)
-        idd = np.zeros((H, W, 2), np.int32)
-        idd[..., 0] = ids
-        idd[..., 1] = rng.choice([60, 100, 120, 400], size=(H, W)) if k % 2 else 100
-        ref = O.denoise(rgba, idd)
-        for dv in DISPLAY_KERNELS:
-            ctx.set_denoise_variant(dv)
-            _assert_same(ctx.denoise(rgba, idd), ref, f"denoise id table case {k} kernel {dv}")
+    # (twice: a width that is not a multiple of four stages tap by tap, one that is stages four taps per 16-byte load)
+    for (W, H) in [(131, 83), (132, 84)]:
+        yy, xx = np.mgrid[0:H, 0:W]
+        slot = lambda v: ((int(v) * 2654435761) & 0xffffffff) >> 25
+        same_slot = [v for v in range(1, 400000) if slot(v) == 5][:40]
+        fields = [1 + yy * W + xx, 1 + (yy // 2) * 16 + (xx // 3) % 16 + 1000 * (xx // 48), np.array(same_slot)[(yy // 4 * 7 + xx // 5) % 40],
+                  np.where((xx % 37 < 2) | (yy % 29 < 2), 9, 1 + (xx // 9 + 11 * (yy // 7)) % 60), np.where(xx % 32 < 20, 0, 3 + yy // 6)]
+        for k, ids in enumerate(fields):
+            rgba = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8)
+            idd = np.zeros((H, W, 2), np.int32)
+            idd[..., 0] = ids
+            idd[..., 1] = rng.choice([60, 100, 120, 400], size=(H, W)) if k % 2 else 100
+            ref = O.denoise(rgba, idd)
+            for dv in DISPLAY_KERNELS:
+                ctx.set_denoise_variant(dv)
+                _assert_same(ctx.denoise(rgba, idd), ref, f"denoise id table case {k} kernel {dv}")
     # radii that differ by one or by many inside a wave, image sizes off the 32 x 16 tile, one object id everywhere
-    for (W, H) in [(67, 35), (130, 50)]:
+    for (W, H) in [(67, 35), (130, 50), (128, 48)]:
         rgba = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8)
         idd = np.zeros((H, W, 2), np.int32)
         idd[..., 0] = 7
