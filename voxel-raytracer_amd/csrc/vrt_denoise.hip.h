@@ -399,6 +399,13 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
     static_assert(kSpanX % PX == 0, "column swizzle");
     const int tid = threadIdx.y * kLanesX + threadIdx.x;
     const int px0 = bx * kTW + threadIdx.x * PX, py = by * kTH + threadIdx.y;
+#ifdef VRT_DENOISE_PHASE   // experiment builds (tools/denoise_phases.sh): the ticks of ONE phase of the tile's first wave, left in the tile's first pixel
+    unsigned long long ph_t = __builtin_readcyclecounter();
+    uint32_t ph_ticks = 0u;
+#define VRT_PH(k) do { const unsigned long long ph_n = __builtin_readcyclecounter(); if (VRT_DENOISE_PHASE == (k)) ph_ticks += (uint32_t)(ph_n - ph_t); ph_t = ph_n; } while (0)
+#else
+#define VRT_PH(k) do { } while (0)
+#endif
     int cid[PX], R[PX];
     int r_hi = 0, r_lo = kMaxR + 1;
     for (int i = tid; i < kIdSlots; i += kThreads) {
@@ -424,6 +431,7 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
             r_lo = R[k] < r_lo ? R[k] : r_lo;
         }
     }
+    VRT_PH(1);   // table init, own pixels loaded, radii
     // a tile of sky (quad.frag:36-39 for every pixel) copies its colours and never stages a window
     if (!__syncthreads_or(r_hi)) {
         if (py < a.height) {
@@ -449,6 +457,7 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
         if (tries == kIdSlots) s_ids->overflow = 1;
     }
     __syncthreads();
+    VRT_PH(2);   // sky vote, claims, barrier
     // stage the 72 x (TH + 40) window: loads of a whole batch are issued before the first is consumed. (All sixteen of a thread's
     // loads requested up front, before its own pixels' -- one round trip per tile instead of three -- measured no faster on the
     // dragon frame and 30 % slower on the 4K frame, whose sky tiles then load their windows for nothing.)
@@ -560,7 +569,9 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
         }
     }
     flush_run();
+    VRT_PH(3);   // staging
     __syncthreads();
+    VRT_PH(4);   // the barrier behind it
 
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -618,6 +629,7 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
         uint32_t seg_mask = 0u;
         for (int sg = 0; sg * kSeg < 2 * rm + PX; ++sg)
             if (sg * kSeg <= u_last && sg * kSeg + kSeg - 1 >= u_first) seg_mask |= 1u << sg;
+        VRT_PH(5);   // radii and common ranges across the wave
         // every pixel's own box (rows_own_box) and what the wave's loops over them would cost against the common rows
         bool own = false;
         if (!s_ids->overflow && a.rows_path != 2) {
@@ -653,7 +665,9 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
             const int cost_common = (y_last - y_first + 1) * (__builtin_popcount(seg_mask) * kSeg * 4 * PX + 4);
             own = a.rows_path == 3 || cost_own * 9 < cost_common * 8;
             if (own) {
+                VRT_PH(6);   // boxes, prices
                 acc = rows_own_box<PX>((LdsF4)s_rec, bx_, hm, wm);
+                VRT_PH(7);   // the own-box walk
             }
         }
         const f4 *row = s_rec + (threadIdx.y + kMaxR - rm) * kStride<PX> + threadIdx.x;  // window row -rm, lane column base
@@ -665,6 +679,7 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
         else
             rows_dispatch<PX, kFull>(row, rm, cid, R, acc, y_first, y_last, seg_mask);
     }
+    VRT_PH(8);   // the common-rows walk (waves that took it)
     if (py >= a.height) return;
 #pragma unroll
     for (int k = 0; k < PX; ++k) {
@@ -678,6 +693,10 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
         const float d = fmax_c(acc.bc[k].y, 1.0f);
         a.out[p] = unorm8(acc.rg[k].x / d) | (unorm8(acc.rg[k].y / d) << 8) | (unorm8(acc.bc[k].x / d) << 16) | (255u << 24);
     }
+#ifdef VRT_DENOISE_PHASE
+    VRT_PH(9);   // divisions and stores
+    if (tid == 0) a.out[(size_t)py * (size_t)a.width + (size_t)px0] = ph_ticks;
+#endif
 }
 
 
