@@ -474,6 +474,7 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
         }
         s_rec[at] = f4{0.0f, 0.0f, 0.0f, 0.0f};
     }
+    VRT_PH(31);   // padding zeroed
     // a thread's taps mostly carry one id after another (its taps lie 3.5 rows apart in one column band): runs of one id are folded
     // in registers and reach the table once per run -- on a close-up where one face fills the tile that is two atomics per thread
     // instead of two per tap on ONE slot
@@ -516,6 +517,8 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
     // pointers aligned: tx0 and the 72-tap rows are multiples of four, so a quad lies wholly inside or outside the image): one
     // 16-byte load for four colours, two for four (voxelID, dist) pairs -- 12 loads per thread instead of 32 -- and four taps that mostly
     // carry ONE id, so the id table sees one run per quad instead of one per tap (its atomics were a fifth of the pass without its sums).
+    // (Measured and not kept: the quad's four first probes of the table read together and atomics only where a tap widens the bound it
+    // reads -- same time: what the staging phase waits for is LDS itself, busy with the other work-group's walk.)
     constexpr int kQuads = kTaps / 4, kQuadIters = (kQuads + kThreads - 1) / kThreads;
     static_assert(kSpanX % 4 == 0 && kTW % 4 == 0 && kMaxR % 4 == 0, "quads never straddle a row or the image's edge");
     const bool quads = (a.width & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.rgba) | reinterpret_cast<uintptr_t>(a.id)) & 15u) == 0u;   // uniform
@@ -534,6 +537,10 @@ __device__ __forceinline__ void tile(const Args &a, const int bx, const int by, 
                 iq1[q] = *reinterpret_cast<const uint4 *>(a.id + g + 2);    // ... g + 2, g + 3
             }
         }
+#ifdef VRT_DENOISE_PHASE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        VRT_PH(32);   // the window's loads requested and arrived
 #pragma unroll
         for (int q = 0; q < kQuadIters; ++q) {
             const int i4 = tid + q * kThreads;
