@@ -33,7 +33,7 @@ def test_test_support_library_is_separate(V):
     lib = C.CDLL(V.TEST_LIB) if os.path.exists(V.TEST_LIB) else None
     assert lib is not None, "make -C voxel-raytracer_amd/csrc builds it"
     for n in ("vrt_test_math", "vrt_test_build_layout", "vrt_test_patch_check", "vrt_test_ray_table", "vrt_test_root0",
-              "vrt_test_view_in_range", "vrt_test_wide_find", "vrt_test_tree_is_opaque"):
+              "vrt_test_view_in_range", "vrt_test_wide_find", "vrt_test_tree_is_opaque", "vrt_test_tile_order"):
         assert hasattr(lib, n), n
 
 

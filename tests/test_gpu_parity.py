@@ -836,6 +836,43 @@ def test_multi_gpu_boundary_rehearsed_on_one_device(V, golden, product_scenes):
         V.Multi([0, 99])
 
 
+def test_order_kernel_sorts_groups_and_counts_the_heavy_ones(V):
+    """tile_order_kernel on synthetic ticks (test-support probe): the order is a permutation with the groups' maxima never rising along
+    it beyond one of its 256 buckets, and the split count behind it is the number of groups above 3/4 of the heaviest -- only when they
+    are at most 64 and the heaviest tile outlasts 3/4 of its even share of all ticks over the wave slots."""
+    rng = np.random.default_rng(5)
+    n = 2040
+    def run(ticks, slots):
+        order, split = V.test_tile_order(ticks, slots)
+        assert np.array_equal(np.sort(order), np.arange(n, dtype=np.uint32))
+        gmax = ticks.reshape(n, 4).max(1).astype(np.int64)
+        top = int(gmax.max())
+        if top:
+            shift = max(0, top.bit_length() - 8)
+            b = gmax[order] >> shift
+            assert np.all(b[:-1] >= b[1:])                       # heaviest bucket first
+        return order, split, gmax
+    light = rng.integers(1000, 3000, size=(n, 4)).astype(np.uint32)
+    # ten heavy groups in a light frame on few slots' worth of work: a frame bound by its longest wave
+    t = light.copy(); heavy = rng.choice(n, 10, replace=False); t[heavy, rng.integers(0, 4, 10)] = rng.integers(90000, 100000, 10)
+    order, split, gmax = run(t, 5120)
+    assert split == 10 and set(order[:10].tolist()) == set(heavy.tolist())
+    # the same frame when the heaviest tile is short against its even share (many more ticks per slot): no split
+    assert run(t, 16)[1] == 0
+    # 100 heavy groups: more than the part-tile waves are meant for
+    t = light.copy(); t[rng.choice(n, 100, replace=False), 0] = 99000
+    assert run(t, 5120)[1] == 0
+    # exactly at the bucket rule: groups in the buckets from 3/4 of the heaviest bucket up count, others do not
+    t = light.copy(); t[5, 1] = 100000; t[6, 2] = 80000; t[7, 3] = 70000
+    order, split, gmax = run(t, 5120)
+    shift = max(0, (100000).bit_length() - 8)
+    want = int(np.count_nonzero((gmax >> shift) >= (((100000 >> shift) * 3 + 3) // 4)))
+    assert split == want == 2 and order[0] == 5
+    # a frame of equal tiles, and a frame without ticks
+    assert run(np.full((n, 4), 5000, np.uint32), 5120)[1] == 0
+    assert run(np.zeros((n, 4), np.uint32), 5120)[1] == 0
+
+
 def test_heaviest_tiles_as_part_tile_waves_never_change_pixels(V, golden, product_scenes):
     """VRT_OPT_HEAVY_TILES: once the scheduler has an order, the general VRT_MODE_FULL kernel traces the few heaviest groups of tiles as
     eight waves per tile. The reference's room (the frame is as long as its longest wave there) at four committed frames: every

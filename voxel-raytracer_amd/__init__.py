@@ -451,6 +451,22 @@ def root0_choice(texels, eye, world_min=(-1023, -1023, -1023), world_max=(1024, 
         raise VrtError(f"vrt_test_root0 failed ({r})")
     return bool(out[0]), int(out[1]), (int(out[2]), int(out[3]), int(out[4])), int(out[5])
 
+def test_tile_order(tile_ticks, wave_slots, device=0):
+    """Device probe (vrt_test_tile_order): the feedback scheduler's order kernel on synthetic per-tile ticks (4 per group) ->
+    (order of the groups, how many groups at its head the general full path tracer would trace as part-tile waves)."""
+    L = test_lib()
+    t = np.ascontiguousarray(tile_ticks, np.uint32).reshape(-1)
+    assert t.size % 4 == 0
+    n = t.size // 4
+    L.vrt_test_tile_order.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    order = np.zeros(n, np.uint32)
+    split = np.zeros(1, np.uint32)
+    r = L.vrt_test_tile_order(device, t.ctypes.data, n, wave_slots, order.ctypes.data, split.ctypes.data)
+    if r:
+        raise VrtError(f"vrt_test_tile_order failed ({r})")
+    return order, int(split[0])
+
+
 
 def tree_is_opaque(texels):
     """Host-only (vrt_test_tree_is_opaque): may VRT_MODE_FULL run without a ray stack on this tree (for an eye in empty space)?"""

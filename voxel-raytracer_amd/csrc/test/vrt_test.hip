@@ -17,6 +17,7 @@
 #include "../vrt_common.hip.h"
 #include "../vrt_full.hip.h"
 #include "../vrt_layout.h"
+#include "../vrt_sched.hip.h"
 
 namespace vrt {
 // exactness probe for the arithmetic contract: out[i] = op(x[i], y[i])
@@ -247,6 +248,28 @@ long vrt_test_build_layout(const uint8_t *texels, size_t used_bytes, uint32_t *r
         info->max_depth = lay.max_depth;
     }
     return (long)lay.records.size();
+}
+
+// The feedback scheduler's order kernel on a synthetic frame: tile_ticks[n_groups * 4] -> order[n_groups] and the split count the
+// kernel leaves behind it (KArgs::split_count). Host arrays, synchronous.
+int vrt_test_tile_order(int device, const uint32_t *tile_ticks, uint32_t n_groups, uint32_t wave_slots, uint32_t *order_out, uint32_t *split_out) {
+    if (!tile_ticks || !order_out || !split_out || n_groups < 1 || n_groups > 36864) return VRT_E_INVALID;
+    void *c = nullptr; (void)c;
+    VRT_HIP(c, hipSetDevice(device));
+    uint32_t *d_cost = nullptr, *d_order = nullptr;
+    VRT_HIP(c, hipMalloc((void **)&d_cost, (size_t)n_groups * 4 * sizeof(uint32_t)));
+    VRT_HIP(c, hipMalloc((void **)&d_order, ((size_t)n_groups + 1) * sizeof(uint32_t)));
+    VRT_HIP(c, hipMemcpy(d_cost, tile_ticks, (size_t)n_groups * 4 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    const size_t lds = (size_t)n_groups * sizeof(uint32_t);
+    if (lds > 48 * 1024) VRT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&vrt::tile_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 36864 * 4));
+    hipLaunchKernelGGL(vrt::tile_order_kernel, dim3(1), dim3(1024), lds, 0, (const uint4 *)d_cost, n_groups, d_order, wave_slots);
+    VRT_HIP(c, hipGetLastError());
+    VRT_HIP(c, hipDeviceSynchronize());
+    VRT_HIP(c, hipMemcpy(order_out, d_order, (size_t)n_groups * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    VRT_HIP(c, hipMemcpy(split_out, d_order + n_groups, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    (void)hipFree(d_cost);
+    (void)hipFree(d_order);
+    return VRT_OK;
 }
 
 }  // extern "C"
