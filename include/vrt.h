@@ -318,7 +318,7 @@ int vrt_set_tile_scheduling(vrt_ctx *ctx, int period);
  *                          general kernel. Scenes with a translucent voxel and eyes inside a medium take the general kernel whatever the
  *                          setting.
  *   VRT_OPT_HEAVY_TILES    1 (default): the general VRT_MODE_FULL kernel, on launches the feedback scheduler has an order for, traces the
- *                          few heaviest groups of tiles (those above 3/4 of the heaviest one's time, when they are at most 64 and the heaviest tile outlasts 3/4 of its even share of the frame) as eight
+ *                          few heaviest groups of tiles (those above 3/4 of the heaviest one's time, at most 64, when the heaviest tile outlasts 3/4 of its even share of the frame) as eight
  *                          waves per 8x8 tile instead of one. A frame of a translucent scene is as long as its longest wave -- dozens of
  *                          rays one after the other, each round as long as the longest of the wave's marches; with 8 pixels per wave that
  *                          is the longest of 8 instead of 64 (profiles/r03_room_critical_path.txt). 0: every tile is one wave. */

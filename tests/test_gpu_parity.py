@@ -838,8 +838,7 @@ def test_multi_gpu_boundary_rehearsed_on_one_device(V, golden, product_scenes):
 
 def test_order_kernel_sorts_groups_and_counts_the_heavy_ones(V):
     """tile_order_kernel on synthetic ticks (test-support probe): the order is a permutation with the groups' maxima never rising along
-    it beyond one of its 256 buckets, and the split count behind it is the number of groups above 3/4 of the heaviest -- only when they
-    are at most 64 and the heaviest tile outlasts 3/4 of its even share of all ticks over the wave slots."""
+    it beyond one of its 256 buckets, and the split count behind it is the number of groups above 3/4 of the heaviest (at most 64) -- only when the heaviest tile outlasts 3/4 of its even share of all ticks over the wave slots."""
     rng = np.random.default_rng(5)
     n = 2040
     def run(ticks, slots):
@@ -859,9 +858,9 @@ def test_order_kernel_sorts_groups_and_counts_the_heavy_ones(V):
     assert split == 10 and set(order[:10].tolist()) == set(heavy.tolist())
     # the same frame when the heaviest tile is short against its even share (many more ticks per slot): no split
     assert run(t, 16)[1] == 0
-    # 100 heavy groups: more than the part-tile waves are meant for
+    # 100 heavy groups: the limit of 64 (the heaviest come first in the order)
     t = light.copy(); t[rng.choice(n, 100, replace=False), 0] = 99000
-    assert run(t, 5120)[1] == 0
+    assert run(t, 5120)[1] == 64
     # exactly at the bucket rule: groups in the buckets from 3/4 of the heaviest bucket up count, others do not
     t = light.copy(); t[5, 1] = 100000; t[6, 2] = 80000; t[7, 3] = 70000
     order, split, gmax = run(t, 5120)

@@ -440,8 +440,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
                 part_wave = true;
                 first = (int)a.group_order[wg / kPerGroup] * kGroupTiles + (int)((wg % kPerGroup) / (uint32_t)kSplitParts);
                 if (lane >= 64 / kSplitParts) return;
-                lx = lane;
-                ly = (int)(wg % (uint32_t)kSplitParts);
+                const int at = (int)(wg % (uint32_t)kSplitParts) * (64 / kSplitParts) + lane;   // the part's pixels in the tile's row-major order
+                lx = at % TW;
+                ly = at / TW;
             } else {
                 wg = wg - n_split * kPerGroup + n_split * (uint32_t)kGroupTiles;   // its place among the whole-tile workgroups
                 if (wg >= (uint32_t)((n_tiles + kGroupTiles - 1) / kGroupTiles * kGroupTiles)) return;   // a workgroup no split group needed

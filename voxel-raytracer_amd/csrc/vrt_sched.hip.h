@@ -72,14 +72,16 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint4 *group_tic
     }
     __syncthreads();
     // KArgs::split_count, kept behind the order: the groups in the buckets from 3/4 of the heaviest bucket up are exactly the first
-    // hist[b - 1] of the order (b their lowest bucket). None when they are more than kSplitMaxGroups, and none unless the frame IS
-    // bound by its longest wave: the heaviest tile's ticks against the ticks of all tiles shared out over the chip's wave slots
-    // (the room at 1080p: 1.7 times as long, at 4K 0.5 -- there the part-waves' extra instructions would only cost)
+    // hist[b - 1] of the order (b their lowest bucket). At most kSplitMaxGroups of them (the heaviest come first in the order; a hard
+    // "none beyond the limit" made a frame whose count hovers around it fall back to whole tiles every other period), and none unless
+    // the frame IS bound by its longest wave: the heaviest tile's ticks against the ticks of all tiles shared out over the chip's wave
+    // slots (the room at 1080p: 1.7 times as long, at 4K 0.5 -- there the part-waves' extra instructions would only cost; a frame of
+    // equal tiles: 0.2)
     if (t == 0) {
         const uint32_t b = ((top >> shift) * 3u + 3u) / 4u;
         const uint32_t heavy = b == 0u ? n_groups : hist[b - 1u];
         const bool tail_bound = wave_slots != 0u && (unsigned long long)top * wave_slots * 4ull > all_ticks * 3ull;   // top > 3/4 of the even share
-        n_split = (top != 0u && tail_bound && heavy <= (uint32_t)kSplitMaxGroups) ? heavy : 0u;
+        n_split = (top != 0u && tail_bound) ? (heavy < (uint32_t)kSplitMaxGroups ? heavy : (uint32_t)kSplitMaxGroups) : 0u;
     }
     __syncthreads();
     if (t == 0) group_order[n_groups] = n_split;
